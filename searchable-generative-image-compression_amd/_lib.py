@@ -1,0 +1,66 @@
+"""ctypes binding of libsgic.so (C ABI in include/sgic.h).  Fails loudly: no library -> ImportError,
+no GPU -> RuntimeError at the first op.  There is deliberately no CPU fallback."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libsgic.so")
+
+if not os.path.exists(_SO):
+    raise ImportError(f"{_SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(hipcc --offload-arch=gfx950). The product path has no CPU fallback.")
+
+lib = C.CDLL(_SO)
+lib.sgic_last_error.restype = C.c_char_p
+lib.sgic_pack12_size.restype = C.c_size_t
+lib.sgic_pack12_size.argtypes = [C.c_size_t]
+
+c_void_p, c_int, c_float, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+
+class SgicError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise SgicError(f"libsgic {what} failed rc={rc}: {lib.sgic_last_error().decode()}")
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("sgic_amd needs an MI355X (gfx950) GPU: the hot path is HIP-only, no CPU fallback")
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """device (or host) pointer of a contiguous tensor / numpy array; None -> NULL"""
+    if t is None:
+        return c_void_p(0)
+    if isinstance(t, torch.Tensor):
+        assert t.is_contiguous(), "sgic kernels take contiguous tensors"
+        return c_void_p(t.data_ptr())
+    return c_void_p(t.ctypes.data)
+
+
+def call(name, *args):
+    """call lib.<name>(*args) -> check return code"""
+    fn = getattr(lib, name)
+    conv = []
+    for a in args:
+        if isinstance(a, (torch.Tensor,)) or a is None or hasattr(a, "ctypes"):
+            conv.append(ptr(a))
+        elif isinstance(a, bool):
+            conv.append(c_int(int(a)))
+        elif isinstance(a, int):
+            conv.append(c_int(a))
+        elif isinstance(a, float):
+            conv.append(c_float(a))
+        else:
+            conv.append(a)
+    check(fn(*conv), name)

@@ -1,0 +1,48 @@
+"""Build csrc/*.hip into an in-tree libsgic.so for gfx950 (hipcc cross-compiles without a GPU)."""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libsgic.so")
+# -ffp-contract=off only for the entropy file: its float ops must be single IEEE operations (bit parity
+# with the CPU oracle); the GEMM/attention files keep fma contraction.
+FLAGS = {"entropy.hip": ["-ffp-contract=off"]}
+
+
+def _newer(src_list, out):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(s) > t for s in src_list)
+
+
+def build(force=False, verbose=False):
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "sgic.h")]
+    objs = []
+    procs = []
+    for s in srcs:
+        o = s[:-4] + ".o"
+        objs.append(o)
+        if force or _newer([s] + hdrs, o):
+            cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", s, "-o", o] + \
+                FLAGS.get(os.path.basename(s), [])
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((s, subprocess.Popen(cmd)))
+    for s, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {s}")
+    if force or procs or _newer(objs, LIB):
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

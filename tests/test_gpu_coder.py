@@ -1,0 +1,171 @@
+"""GPU parity of the HIP entropy-coder kernels (through the C ABI) against the C oracle and the golden
+vectors produced by the real reference coder.  Bit-exact: this is integer/byte work."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tab(golden_dir):
+    t = np.load(os.path.join(golden_dir, "cdf_table.npz"))
+    return t["cdf"], t["cdf_length"], t["offset"]
+
+
+@pytest.fixture(scope="module")
+def codec(tab):
+    import sgic_amd  # noqa
+    from sgic_amd.entropy.MLCodec_rans import RansDecoder, RansEncoder
+    enc, dec = RansEncoder(False, 1), RansDecoder(1)
+    g = enc.add_cdf(*tab)
+    assert dec.add_cdf(*tab) == g
+    return enc, dec, g
+
+
+def test_facade_kats_bit_exact(golden_dir, codec):
+    enc, dec, g = codec
+    k = np.load(os.path.join(golden_dir, "rans_kats.npz"))
+    for i in range(int(k["n"])):
+        sym, idx, cuts = k[f"sym_{i}"], k[f"idx_{i}"], k[f"cuts_{i}"]
+        enc.reset()
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            enc.encode_with_indexes(sym[a:b], idx[a:b], g)
+        enc.flush()
+        got = enc.get_encoded_stream()
+        assert got.tobytes() == k[f"stream_{i}"].tobytes(), f"kat {i}"
+        dec.set_stream(got)
+        out = np.concatenate([dec.decode_stream(idx[a:b], g) for a, b in zip(cuts[:-1], cuts[1:])])
+        assert np.array_equal(out, np.where(idx < 0, 0, sym)), f"kat {i} decode"
+
+
+def test_degenerate_streams(codec, tab):
+    enc, dec, g = codec
+    enc.reset()
+    enc.encode_with_indexes(np.zeros(16, np.int16), -np.ones(16, np.int16), g)
+    enc.flush()
+    assert enc.get_encoded_stream().tobytes() == bytes([1, 0, 0, 0x80, 0])
+    enc.reset()
+    enc.flush()
+    assert enc.get_encoded_stream().tobytes() == bytes([1, 0, 0, 0x80, 0])
+    # tiny high-entropy stream (3 symbols of freq 1): the reference corrupts its heap here
+    sym, idx = np.array([-3, 2, 0], np.int16), np.zeros(3, np.int16)
+    enc.reset()
+    enc.encode_with_indexes(sym, idx, g)
+    enc.flush()
+    s = enc.get_encoded_stream()
+    assert s.tobytes() == orc.rans_encode(sym, idx, orc.Table(*tab))
+    dec.set_stream(s)
+    assert np.array_equal(dec.decode_stream(idx, g), sym)
+
+
+def test_truncated_stream_is_detected(codec):
+    enc, dec, g = codec
+    rng = np.random.default_rng(0)
+    idx = rng.integers(0, 256, 512).astype(np.int16)
+    sym = rng.integers(-5, 6, 512).astype(np.int16)
+    enc.reset()
+    enc.encode_with_indexes(sym, idx, g)
+    enc.flush()
+    s = enc.get_encoded_stream()
+    dec.set_stream(s[: len(s) // 2])
+    with pytest.raises(RuntimeError):
+        dec.decode_stream(idx, g)
+
+
+def test_batched_encode_decode_vs_oracle_full_size(tab):
+    """B=32 images x 4096 symbols (config 2) and B=16 x 16384 (config 5): device-resident batch API,
+    every stream byte-identical to the C oracle; decode in 4 cursor-continuing calls."""
+    import sgic_amd  # noqa
+    from sgic_amd._lib import call
+    from sgic_amd.entropy.MLCodec_rans import _Tables
+    T = _Tables()
+    g = T.add(*tab)
+    otab = orc.Table(*tab)
+    scale_table = np.exp(np.linspace(np.log(0.11), np.log(64.0), 256))
+    dev = torch.device("cuda:0")
+    for (B, n) in [(32, 4096), (16, 16384), (3, 1000)]:
+        rng = np.random.default_rng(B * 7 + n)
+        idx = rng.integers(0, 120, size=(B, n)).astype(np.int16)
+        idx[rng.random((B, n)) < 0.4] = -1
+        sym = np.rint(rng.standard_normal((B, n)) * scale_table[np.maximum(idx, 0)] * 1.2).astype(np.int16)
+        sym[rng.random((B, n)) < 0.002] = 3000  # a few bypass symbols
+        d_sym, d_idx = torch.from_numpy(sym).to(dev), torch.from_numpy(idx).to(dev)
+        cap = 2 * n + 64
+        out = torch.zeros(B, cap, dtype=torch.uint8, device=dev)
+        off = torch.zeros(B, dtype=torch.int32, device=dev)
+        ln = torch.zeros(B, dtype=torch.int32, device=dev)
+        err = torch.zeros(B, dtype=torch.int32, device=dev)
+        call("sgic_rans_encode_batch", T.handles[g], d_sym, d_idx, B, n, out, cap, off, ln, err)
+        assert int(err.abs().sum()) == 0
+        h_out, h_off, h_len = out.cpu().numpy(), off.cpu().numpy(), ln.cpu().numpy()
+        for b in range(B):
+            got = h_out[b, h_off[b]:h_off[b] + h_len[b]].tobytes()
+            assert got == orc.rans_encode(sym[b], idx[b], otab), (B, n, b)
+        # decode: 4 calls of n/4 each, continuing the cursor (like the 4 prior steps)
+        state = torch.zeros(B, 4, dtype=torch.int32, device=dev)
+        call("sgic_rans_decode_init_batch", out, cap, off, ln, B, state)
+        dec = torch.zeros(B, n, dtype=torch.int16, device=dev)
+        q = n // 4
+        for k in range(4):
+            a = k * q
+            cnt = q if k < 3 else n - a
+            call("sgic_rans_decode_batch", T.handles[g], out, cap, off, ln, B, state, d_idx.view(-1)[a:],
+                 cnt, n, dec.view(-1)[a:], n)
+        assert int(state[:, 2].abs().sum()) == 0
+        assert np.array_equal(dec.cpu().numpy(), np.where(idx < 0, 0, sym))
+
+
+def test_pack12_batch_vs_oracle():
+    import sgic_amd  # noqa
+    from sgic_amd._lib import call, lib
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(1)
+    for (B, n) in [(32, 32), (16, 128), (5, 33), (1, 1)]:
+        idx = rng.integers(0, 4096, size=(B, n)).astype(np.int32)
+        nb = lib.sgic_pack12_size(n)
+        d = torch.from_numpy(idx).to(dev)
+        out = torch.zeros(B, nb, dtype=torch.uint8, device=dev)
+        call("sgic_pack12_batch", d, B, n, out)
+        h = out.cpu().numpy()
+        for b in range(B):
+            assert h[b].tobytes() == orc.pack12(idx[b].astype(np.int16)), (B, n, b)
+        back = torch.zeros(B, n, dtype=torch.int32, device=dev)
+        call("sgic_unpack12_batch", out, B, n, back)
+        assert np.array_equal(back.cpu().numpy(), idx)
+
+
+def test_quant_step_vs_oracle_bit_exact():
+    """Fused masked quantise + index build (K9): NHWC HIP kernel vs the NCHW C oracle, same fp32 inputs."""
+    import sgic_amd  # noqa
+    from sgic_amd._lib import call
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(11)
+    for (B, H, W) in [(4, 8, 8), (2, 16, 16), (1, 3, 5)]:
+        C = 64
+        y = (rng.standard_normal((B, C, H, W)) * 3).astype(np.float32)
+        y[0, :, 0, 0] = np.float32(0.5) + np.arange(C, dtype=np.float32)  # exact ties -> round-half-even
+        sc = np.exp(rng.uniform(np.log(0.05), np.log(70.0), size=(B, C, H, W))).astype(np.float32)
+        mu = rng.standard_normal((B, C, H, W)).astype(np.float32)
+        mu[0, :, 0, 0] = 0
+        nhwc = lambda a: np.ascontiguousarray(a.transpose(0, 2, 3, 1))
+        d_y = torch.from_numpy(nhwc(y)).to(dev).view(-1, C)
+        sm = torch.from_numpy(np.concatenate([nhwc(sc), nhwc(mu)], axis=-1)).to(dev).view(-1, 2 * C)
+        yhat = torch.zeros(B * H * W, 2 * C, device=dev)
+        sym = torch.zeros(B, 4, C // 4, H, W, dtype=torch.int16, device=dev)
+        idx = torch.zeros_like(sym)
+        for k in range(4):
+            call("sgic_quant_step", d_y, sm, sm.view(-1)[C:], 2 * C, yhat, 2 * C, B, H, W, C, k, 0.12, sym, idx)
+        h_sym, h_idx = sym.cpu().numpy(), idx.cpu().numpy()
+        h_yhat = yhat.cpu().numpy()[:, :C].reshape(B, H, W, C).transpose(0, 3, 1, 2)
+        for b in range(B):
+            ref_hat = np.zeros((C, H, W), np.float32)
+            for k in range(4):
+                s, i = orc.quant_step(y[b], sc[b], mu[b], k, 0.12, ref_hat)
+                assert np.array_equal(h_sym[b, k], s), (B, H, W, b, k)
+                assert np.array_equal(h_idx[b, k], i), (B, H, W, b, k)
+            assert np.array_equal(h_yhat[b], ref_hat)
