@@ -48,8 +48,12 @@ def ptr(t):
     return c_void_p(t.ctypes.data)
 
 
+_NO_STREAM = {"sgic_pmf_to_quantized_cdf", "sgic_cdf_table_create"}
+
+
 def call(name, *args):
-    """call lib.<name>(*args) -> check return code"""
+    """call lib.<name>(*args, current HIP stream) -> check return code.  Every device entry point of
+    the C ABI takes the stream as its LAST argument; it is appended here."""
     fn = getattr(lib, name)
     conv = []
     for a in args:
@@ -63,4 +67,6 @@ def call(name, *args):
             conv.append(c_float(a))
         else:
             conv.append(a)
+    if name not in _NO_STREAM:
+        conv.append(stream())
     check(fn(*conv), name)
