@@ -92,6 +92,80 @@ int sgic_index_step(const float *d_scales, int ld_sm, int B, int H, int W, int C
 int sgic_dequant_step(const int16_t *d_sym, const float *d_means, int ld_sm, float *d_yhat, int ld_yhat, int B,
                       int H, int W, int C, int k, sgic_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Transform kernels (fp32, row-major "token x channel" = NHWC activations).  They replace the stock
+ * ATen ops under the reference's nn.Modules; reference call sites are cited per function.
+ * ------------------------------------------------------------------------------------------- */
+#define SGIC_ACT_NONE 0
+#define SGIC_ACT_GELU 1  /* exact erf GELU (nn.GELU default) */
+#define SGIC_ACT_SILU 2
+#define SGIC_ACT_TANH 3
+#define SGIC_ACT_LRELU 4 /* LeakyReLU(0.01) */
+
+/* C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) + R[M,N]   -- nn.Linear / 1x1 Conv2d / im2col'd convs
+ * (titok/blocks.py:37-64, blocks/swin_transformer.py:30-39,86,92, models/cross_blocks.py:55-68,
+ * blocks/conv_blocks.py:63-67, blocks/dcvc.py:17-23,42-43).  fp32-input MFMA (exact fp32), fixed k
+ * order => batch-invariant.  K, lda, ldw multiples of 4; A, W 16-byte aligned; bias/R optional.
+ * Row maps row(m) = (m / seg) * seg_stride + m % seg (seg = 0: identity) let A be read from / C be
+ * written to a token slice [:, a:b] of an (n, L, C) buffer in place (models/cross_blocks.py:87-94). */
+int sgic_gemm_f32(const float *d_A, int lda, const float *d_W, int ldw, const float *d_bias, const float *d_R,
+                  int ldr, float *d_C, int ldc, int M, int N, int K, int act, int a_seg, int a_seg_stride,
+                  int c_seg, int c_seg_stride, sgic_stream_t stream);
+
+/* Row LayerNorm, biased variance, eps inside sqrt, optional fused SiLU (act = SGIC_ACT_SILU); rows of x
+ * and y addressed through the same kind of segment map (titok/blocks.py:36,42,
+ * blocks/swin_transformer.py:135,142, blocks/conv_blocks.py:62, models/cross_blocks.py:62,67). */
+int sgic_layernorm_f32(const float *d_x, int ldx, int xseg, int xseg_stride, const float *d_gamma,
+                       const float *d_beta, float *d_y, int ldy, int yseg, int yseg_stride, int M, int C, float eps,
+                       int act, sgic_stream_t stream);
+
+/* softmax(scale * Q K^T + bias) V for 64-wide heads; q/k/v/out are row-strided "token x (heads*64)"
+ * matrices, head h at column h*64.  Sequence s, token t lives in row d_rowmap[s*L+t] (null: s*L+t) --
+ * the Swin cyclic shift + window partition is such a map (blocks/swin_transformer.py:94-128).
+ * d_bias: (nvar, L, L) additive (relative-position table + -inf shift masks), variant per sequence in
+ * d_biasvar (null: 0).  nn.MultiheadAttention (titok/blocks.py:50-54) is the rowmap = bias = null case. */
+int sgic_attention_f32(const float *d_q, int ldq, const float *d_k, int ldk, const float *d_v, int ldv,
+                       float *d_out, int ldo, int L, int nseq, int nheads, const int32_t *d_rowmap,
+                       const float *d_bias, const int32_t *d_biasvar, float scale, sgic_stream_t stream);
+
+/* im2col of non-overlapping PxP patches of an NCHW image with x*mul+add fused; patch rows in plain
+ * (b,gy,gx) order or 16x16-tile-major (tile16) order (codec_sq_fixbpp.py:855,119; titok/blocks.py:98-100). */
+int sgic_im2col_patch(const float *d_x, int B, int C, int H, int W, int P, float mul, float add, int tile16,
+                      float *d_out, sgic_stream_t stream);
+/* [cls+pos0 ; emb+pos ; lat+latpos] token assembly (codec_sq_fixbpp.py:127-138). */
+int sgic_assemble_tokens(const float *d_emb, const float *d_cls, const float *d_pos, const float *d_lat,
+                         const float *d_latpos, int N, int P, int T, int D, float *d_out, sgic_stream_t stream);
+/* out[n*oseg+l,:] = in[n*iseg+l,:] + vec[l,:]  (models/cross_blocks.py:82-84); vec may be null. */
+int sgic_add_rows_bcast(const float *d_in, int ldi, int iseg, const float *d_vec, float *d_out, int ldo, int oseg,
+                        int Nn, int Lr, int D, sgic_stream_t stream);
+/* depthwise kxk conv, NHWC, weights [k*k][C], optional per-channel prescale (blocks/conv_blocks.py:74-75,
+ * blocks/dcvc.py:21,35). */
+int sgic_dwconv_nhwc(const float *d_x, const float *d_w, const float *d_bias, const float *d_prescale, float *d_y,
+                     int B, int H, int W, int C, int k, int tile16, sgic_stream_t stream);
+/* im2col of the 2x2/s2 conv in feat_out (codec_sq_fixbpp.py:90): out[(b,y/2,x/2)][(ky*2+kx)*C+c]. */
+int sgic_im2col_2x2(const float *d_x, int B, int H, int W, int C, int tile16, float *d_out, sgic_stream_t stream);
+/* ConvFFN3 gate (blocks/dcvc.py:50-53). */
+int sgic_gated_lrelu(const float *d_x, float *d_out, int M, int C2, sgic_stream_t stream);
+/* y = x * v (mode 0) or x / max(v, 0.5) (mode 1), v row m % vrows (sq_bottleneck.py:111,117;
+ * compression_model.py:325-326,355). */
+int sgic_colop(const float *d_x, int ldx, const float *d_v, int ldv, int vrows, float *d_y, int ldy, int M, int C,
+               int mode, sgic_stream_t stream);
+/* out[n][t][c] = in[n*in_seq_stride + c*T + t]  ("fake 2-D" reshape, codec_sq_fixbpp.py:175-177). */
+int sgic_fake2d_transpose(const float *d_in, long in_seq_stride, float *d_out, int N, int T, int D,
+                          sgic_stream_t stream);
+/* l2-normalised nearest-code search (titok/quantizer.py:46-61). */
+int sgic_vq_argmin(const float *d_z, int ldz, const float *d_codebook, int ncodes, int dim, int M, int l2norm,
+                   int32_t *d_idx, sgic_stream_t stream);
+/* CLIP preprocessing, bit-exact with ToPILImage -> PIL bicubic antialias resize -> center crop ->
+ * ToTensor -> Normalize (compress.py:70-71).  Coefficient tables are Pillow's 22-bit fixed-point ints. */
+int sgic_clip_preprocess(const float *d_x, long img_stride, long ch_stride, int ldx, int B, int H, int W, int OH,
+                         int OW, int S, int top, int left, const int32_t *d_bounds_h, const int32_t *d_kk_h,
+                         int ksize_h, const int32_t *d_bounds_v, const int32_t *d_kk_v, int ksize_v,
+                         const float *mean3, const float *std3, uint8_t *d_tmp_u8, uint8_t *d_tmp_h, float *d_out,
+                         sgic_stream_t stream);
+/* unit-normalise rows + u8 quantise (compress.py:73,77). */
+int sgic_l2norm_u8(const float *d_x, int ldx, int M, int D, float *d_unit, uint8_t *d_q, sgic_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsgic.so")
 # -ffp-contract=off only for the entropy file: its float ops must be single IEEE operations (bit parity
 # with the CPU oracle); the GEMM/attention files keep fma contraction.
-FLAGS = {"entropy.hip": ["-ffp-contract=off"]}
+FLAGS = {"entropy.hip": ["-ffp-contract=off"], "misc.hip": ["-ffp-contract=off"]}
 
 
 def _newer(src_list, out):

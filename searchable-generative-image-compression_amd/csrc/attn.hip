@@ -1,0 +1,196 @@
+// fp32 multi-head attention for head_dim 64 on the CDNA4 matrix cores (flash style, online softmax).
+//
+// Serves every attention on the path, all of which have 64-wide heads:
+//   * TiTok ViT-L blocks, L=289, 16 heads            (titok/blocks.py:50-54 nn.MultiheadAttention)
+//   * cross blocks, L=545, 12 heads                   (models/cross_blocks.py:88 via ResidualAttentionBlock)
+//   * Swin window attention, L=256 per 16x16 window, dense additive bias (relative position table +
+//     the -inf shift masks), cyclic shift folded into a row map   (blocks/swin_transformer.py:94-128)
+//   * CLIP ViT-B/32, L=50, 12 heads                   (open_clip image tower, compress.py:72)
+//
+// One workgroup = 4 waves = 128 query rows of one (sequence, head); each wave owns 32 query rows.
+// K/V tiles of 32 keys are staged in LDS by the whole workgroup.  Per tile and wave:
+//   S^T = K . Q^T      32 x v_mfma_f32_32x32x2_f32   (A = K tile from LDS, B = Q^T kept in 32 VGPRs)
+//   online softmax     the accumulator layout puts ONE query row on each lane (col = lane&31) with 16
+//                      of its 32 keys in registers, so max/sum are 15 in-register ops + one
+//                      cross-half shuffle
+//   O^T += V^T . P^T   32 x MFMA; P^T is consumed straight from the S^T accumulator registers (the MFMA
+//                      k index only has to pair the same key on both operands), V^T from LDS
+// q is pre-scaled by `scale` (0.125 is a power of two, so this equals scaling the scores).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define AT_KT 32      // keys per tile
+#define AT_LDK 68     // padded row stride (floats) of the K tile: 272 B -> conflict-free ds_read_b128
+#define AT_LDV 64
+
+struct AttnArgs {
+  const float *q, *k, *v;  // row-strided, head h at column offset h*64
+  float *out;
+  int ldq, ldk, ldv, ldo;
+  int L, nseq, nheads;
+  const int *rowmap;    // [nseq*L] row of (seq, token) or null => seq*L + token
+  const float *bias;    // [nvar][L][L] additive bias or null
+  const int *biasvar;   // [nseq] variant index or null (=> variant 0)
+  float scale;
+};
+
+__global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float sK[AT_KT * AT_LDK];
+  __shared__ __attribute__((aligned(16))) float sV[AT_KT * AT_LDV];
+  __shared__ int sRow[AT_KT];
+
+  const int qblocks = (a.L + 127) / 128;
+  int bid = blockIdx.x;
+  const int qb = bid % qblocks;
+  bid /= qblocks;
+  const int head = bid % a.nheads;
+  const int seq = bid / a.nheads;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 31, lh = lane >> 5;
+  const int q_tok = qb * 128 + wave * 32 + lq;  // this lane's query token
+  const bool q_ok = q_tok < a.L;
+  const int q_tok_c = q_ok ? q_tok : a.L - 1;
+  const long q_row = a.rowmap ? a.rowmap[(long)seq * a.L + q_tok_c] : (long)seq * a.L + q_tok_c;
+  const int hc = head * 64;
+
+  // Q^T fragment: lane (q, h) holds Q[q][(2c+h)*4 + t], c=0..7, t=0..3  (pairs with the K read below)
+  float qf[32];
+  {
+    const float *qp = a.q + q_row * a.ldq + hc;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const f32x4 v4 = *reinterpret_cast<const f32x4 *>(qp + (2 * c + lh) * 4);
+#pragma unroll
+      for (int t = 0; t < 4; t++) qf[c * 4 + t] = v4[t] * a.scale;
+    }
+  }
+
+  f32x16 o0, o1;  // O^T: rows d (0..31 / 32..63), col = query
+#pragma unroll
+  for (int e = 0; e < 16; e++) o0[e] = 0.f, o1[e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;  // l_run: this lane's partial row sum (its 16 keys per tile)
+
+  const float *bias_base = nullptr;
+  if (a.bias) {
+    const int var = a.biasvar ? a.biasvar[seq] : 0;
+    bias_base = a.bias + ((long)var * a.L + q_tok_c) * a.L;
+  }
+
+  const int ntiles = (a.L + AT_KT - 1) / AT_KT;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int key0 = kt * AT_KT;
+    __syncthreads();  // previous tile fully consumed
+    if (tid < AT_KT) {
+      const int tok = key0 + tid;
+      sRow[tid] = tok < a.L ? (int)(a.rowmap ? a.rowmap[(long)seq * a.L + tok] : (long)seq * a.L + tok) : -1;
+    }
+    __syncthreads();
+    {  // stage K and V: 32 keys x 16 float4 each = 512 float4 per operand, 2 per thread
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int f = tid + 256 * i, kr = f >> 4, c4 = f & 15;
+        const int row = sRow[kr];
+        f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+        if (row >= 0) {
+          kv = *reinterpret_cast<const f32x4 *>(a.k + (long)row * a.ldk + hc + c4 * 4);
+          vv = *reinterpret_cast<const f32x4 *>(a.v + (long)row * a.ldv + hc + c4 * 4);
+        }
+        *reinterpret_cast<f32x4 *>(&sK[kr * AT_LDK + c4 * 4]) = kv;
+        *reinterpret_cast<f32x4 *>(&sV[kr * AT_LDV + c4 * 4]) = vv;
+      }
+    }
+    __syncthreads();
+
+    // ---- S^T[key][q] = sum_d K[key][d] * Q[q][d] ----
+    f32x16 s;
+#pragma unroll
+    for (int e = 0; e < 16; e++) s[e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const f32x4 kf = *reinterpret_cast<const f32x4 *>(&sK[lq * AT_LDK + (2 * c + lh) * 4]);
+#pragma unroll
+      for (int t = 0; t < 4; t++) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t], qf[c * 4 + t], s, 0, 0, 0);
+    }
+    // lane holds keys key0 + (e&3) + 8*(e>>2) + 4*lh  for its query
+    if (bias_base) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4++) {
+        const int kb = key0 + 8 * g4 + 4 * lh;
+        if (kb + 3 < a.L) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias_base + kb);
+#pragma unroll
+          for (int t = 0; t < 4; t++) s[g4 * 4 + t] += b4[t];
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; t++)
+            if (kb + t < a.L) s[g4 * 4 + t] += bias_base[kb + t];
+        }
+      }
+    }
+    if (key0 + AT_KT > a.L) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (key >= a.L) s[e] = -INFINITY;
+      }
+    }
+    float mx = s[0];
+#pragma unroll
+    for (int e = 1; e < 16; e++) mx = fmaxf(mx, s[e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // whole row masked so far
+    const float alpha = expf(m_run - m_use);               // m_run = -inf -> 0
+    float psum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      s[e] = expf(s[e] - m_use);
+      psum += s[e];
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int e = 0; e < 16; e++) o0[e] *= alpha, o1[e] *= alpha;
+
+    // ---- O^T[d][q] += sum_key V[key][d] * P[q][key];  k-step e pairs key (e&3)+8*(e>>2)+4*lh ----
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const int key = (e & 3) + 8 * (e >> 2) + 4 * lh;
+      const float v0 = sV[key * AT_LDV + lq], v1 = sV[key * AT_LDV + 32 + lq];
+      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[e], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[e], o1, 0, 0, 0);
+    }
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  if (q_ok) {
+    float *op = a.out + q_row * a.ldo + hc;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; g4++) {
+      const int d = 8 * g4 + 4 * lh;
+      f32x4 w0, w1;
+#pragma unroll
+      for (int t = 0; t < 4; t++) w0[t] = o0[g4 * 4 + t] * inv, w1[t] = o1[g4 * 4 + t] * inv;
+      *reinterpret_cast<f32x4 *>(op + d) = w0;
+      *reinterpret_cast<f32x4 *>(op + 32 + d) = w1;
+    }
+  }
+}
+
+extern "C" int sgic_attention_f32(const float *d_q, int ldq, const float *d_k, int ldk, const float *d_v, int ldv,
+                                  float *d_out, int ldo, int L, int nseq, int nheads, const int32_t *d_rowmap,
+                                  const float *d_bias, const int32_t *d_biasvar, float scale, sgic_stream_t stream) {
+  SGIC_REQUIRE(d_q && d_k && d_v && d_out && L > 0 && nseq > 0 && nheads > 0, "args");
+  SGIC_REQUIRE((ldq & 3) == 0 && (ldk & 3) == 0 && (ldv & 3) == 0 && (ldo & 3) == 0, "row strides must be multiples of 4");
+  SGIC_REQUIRE(ldq >= nheads * 64 && ldk >= nheads * 64 && ldv >= nheads * 64 && ldo >= nheads * 64, "head_dim is 64");
+  SGIC_REQUIRE((((uintptr_t)d_q | (uintptr_t)d_k | (uintptr_t)d_v | (uintptr_t)d_out) & 15) == 0, "16-byte alignment");
+  SGIC_REQUIRE(!d_bias || (L & 3) == 0, "bias needs L % 4 == 0");
+  AttnArgs a{d_q, d_k, d_v, d_out, ldq, ldk, ldv, ldo, L, nseq, nheads, d_rowmap, d_bias, d_biasvar, scale};
+  const long grid = (long)nseq * nheads * ((L + 127) / 128);
+  attn_f32_kernel<<<(unsigned)grid, 256, 0, to_stream(stream)>>>(a);
+  return sgic::check_launch("attn_f32_kernel");
+}

@@ -1,0 +1,456 @@
+// HBM-bound data-movement / elementwise kernels of the transform path (all fp32, float4-vectorised,
+// coalesced along the channel axis).  Feature maps are "token x channel" (NHWC); the 16x16-tile-major
+// row order TM16 (row = ((b*nH + y/16)*nW + x/16)*256 + (y%16)*16 + x%16) makes the reference's
+// tile <-> stack rearranges (models/codec_sq_fixbpp.py:123-125, models/cross_blocks.py:78-79,96-97)
+// the identity, so no gather/scatter pass is ever needed.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ long fmap_row(int b, int y, int x, int H, int W, int tile16) {
+  if (!tile16) return ((long)b * H + y) * W + x;
+  const int nH = H >> 4, nW = W >> 4;
+  return ((((long)b * nH + (y >> 4)) * nW + (x >> 4)) << 8) + ((y & 15) << 4) + (x & 15);
+}
+
+#define GRID_STRIDE(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
+static inline unsigned ew_grid(long n) {
+  long g = (n + 255) / 256;
+  return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+// ------------------------------------------------------------------------------------------------
+// im2col for non-overlapping PxP patches of an NCHW image, with the affine x*mul+add fused
+// (codec: x*0.5+0.5 then patch_embed, codec_sq_fixbpp.py:855 + titok/blocks.py:98-100; CLIP conv1).
+// out[(patch), c*P*P + ky*P + kx]; patch order plain (b,gy,gx) or TM16 over the patch grid.
+// ------------------------------------------------------------------------------------------------
+__global__ void im2col_patch_kernel(const float *__restrict__ x, int B, int C, int H, int W, int P, float mul, float add,
+                                    int tile16, float *__restrict__ out) {
+  const int gh = H / P, gw = W / P, K = C * P * P, P4 = P >> 2;
+  const long total = (long)B * gh * gw * C * P * P4;  // float4 units
+  GRID_STRIDE(i, total) {
+    long t = i;
+    const int kx4 = (int)(t % P4);
+    t /= P4;
+    const int ky = (int)(t % P);
+    t /= P;
+    const int c = (int)(t % C);
+    t /= C;
+    const int gx = (int)(t % gw);
+    t /= gw;
+    const int gy = (int)(t % gh);
+    const int b = (int)(t / gh);
+    f32x4 v = *reinterpret_cast<const f32x4 *>(x + (((long)b * C + c) * H + gy * P + ky) * W + gx * P + kx4 * 4);
+#pragma unroll
+    for (int e = 0; e < 4; e++) v[e] = v[e] * mul + add;
+    const long row = fmap_row(b, gy, gx, gh, gw, tile16);
+    *reinterpret_cast<f32x4 *>(out + row * K + (c * P + ky) * P + kx4 * 4) = v;
+  }
+}
+
+extern "C" int sgic_im2col_patch(const float *d_x, int B, int C, int H, int W, int P, float mul, float add, int tile16,
+                                 float *d_out, sgic_stream_t stream) {
+  SGIC_REQUIRE(d_x && d_out && B > 0 && C > 0 && P >= 4 && (P & 3) == 0 && H % P == 0 && W % P == 0, "args");
+  SGIC_REQUIRE(!tile16 || ((H / P) % 16 == 0 && (W / P) % 16 == 0), "tile-major order needs a patch grid multiple of 16");
+  SGIC_REQUIRE((W & 3) == 0 && ((uintptr_t)d_x & 15) == 0 && ((uintptr_t)d_out & 15) == 0, "alignment");
+  const long total = (long)B * (H / P) * (W / P) * C * P * (P / 4);
+  im2col_patch_kernel<<<ew_grid(total), 256, 0, to_stream(stream)>>>(d_x, B, C, H, W, P, mul, add, tile16, d_out);
+  return sgic::check_launch("im2col_patch_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Token assembly:  out[n, 0]       = cls + pos[0]
+//                  out[n, 1+p]     = emb[n*P + p] + pos[1+p]          p < P
+//                  out[n, 1+P+t]   = lat[t] + latpos[t]               t < T   (T may be 0)
+// (codec_sq_fixbpp.py:127-138; CLIP class/positional embedding)
+// ------------------------------------------------------------------------------------------------
+__global__ void assemble_tokens_kernel(const float *__restrict__ emb, const float *__restrict__ cls,
+                                       const float *__restrict__ pos, const float *__restrict__ lat,
+                                       const float *__restrict__ latpos, int N, int P, int T, int D,
+                                       float *__restrict__ out) {
+  const int L = 1 + P + T, D4 = D >> 2;
+  const long total = (long)N * L * D4;
+  GRID_STRIDE(i, total) {
+    const int d4 = (int)(i % D4);
+    const long r = i / D4;
+    const int l = (int)(r % L);
+    const int n = (int)(r / L);
+    f32x4 a, b;
+    if (l == 0) {
+      a = reinterpret_cast<const f32x4 *>(cls)[d4];
+      b = reinterpret_cast<const f32x4 *>(pos)[d4];
+    } else if (l <= P) {
+      a = reinterpret_cast<const f32x4 *>(emb + ((long)n * P + (l - 1)) * D)[d4];
+      b = reinterpret_cast<const f32x4 *>(pos + (long)l * D)[d4];
+    } else {
+      a = reinterpret_cast<const f32x4 *>(lat + (long)(l - 1 - P) * D)[d4];
+      b = reinterpret_cast<const f32x4 *>(latpos + (long)(l - 1 - P) * D)[d4];
+    }
+    reinterpret_cast<f32x4 *>(out + r * D)[d4] = a + b;
+  }
+}
+
+extern "C" int sgic_assemble_tokens(const float *d_emb, const float *d_cls, const float *d_pos, const float *d_lat,
+                                    const float *d_latpos, int N, int P, int T, int D, float *d_out,
+                                    sgic_stream_t stream) {
+  SGIC_REQUIRE(d_emb && d_cls && d_pos && d_out && N > 0 && P > 0 && T >= 0 && D > 0 && (D & 3) == 0, "args");
+  SGIC_REQUIRE(T == 0 || (d_lat && d_latpos), "latent tokens");
+  const long total = (long)N * (1 + P + T) * (D / 4);
+  assemble_tokens_kernel<<<ew_grid(total), 256, 0, to_stream(stream)>>>(d_emb, d_cls, d_pos, d_lat, d_latpos, N, P, T, D,
+                                                                         d_out);
+  return sgic::check_launch("assemble_tokens_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[n*oseg + l, :] = in[n*iseg + l, :] + vec[l, :]     l < Lr   (positional-embedding adds into a
+// slice of a larger token buffer: models/cross_blocks.py:82-84).  vec may be null (pure strided copy).
+// ------------------------------------------------------------------------------------------------
+__global__ void add_rows_bcast_kernel(const float *__restrict__ in, int ldi, int iseg, const float *__restrict__ vec,
+                                      float *__restrict__ out, int ldo, int oseg, int Nn, int Lr, int D) {
+  const int D4 = D >> 2;
+  const long total = (long)Nn * Lr * D4;
+  GRID_STRIDE(i, total) {
+    const int d4 = (int)(i % D4);
+    const long r = i / D4;
+    const int l = (int)(r % Lr);
+    const int n = (int)(r / Lr);
+    f32x4 a = reinterpret_cast<const f32x4 *>(in + ((long)n * iseg + l) * ldi)[d4];
+    if (vec) a += reinterpret_cast<const f32x4 *>(vec + (long)l * D)[d4];
+    reinterpret_cast<f32x4 *>(out + ((long)n * oseg + l) * ldo)[d4] = a;
+  }
+}
+
+extern "C" int sgic_add_rows_bcast(const float *d_in, int ldi, int iseg, const float *d_vec, float *d_out, int ldo,
+                                   int oseg, int Nn, int Lr, int D, sgic_stream_t stream) {
+  SGIC_REQUIRE(d_in && d_out && Nn > 0 && Lr > 0 && D > 0 && (D & 3) == 0 && (ldi & 3) == 0 && (ldo & 3) == 0, "args");
+  const long total = (long)Nn * Lr * (D / 4);
+  add_rows_bcast_kernel<<<ew_grid(total), 256, 0, to_stream(stream)>>>(d_in, ldi, iseg, d_vec, d_out, ldo, oseg, Nn, Lr, D);
+  return sgic::check_launch("add_rows_bcast_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Depthwise kxk conv, stride 1, zero padding k/2, NHWC (plain or TM16 rows); weights re-laid as
+// [k*k][C]; optional per-channel pre-scale (ConvNeXt applies layer_scale BEFORE the conv,
+// blocks/conv_blocks.py:74-75; DepthConv dw3x3, blocks/dcvc.py:21,35).
+// ------------------------------------------------------------------------------------------------
+__global__ void dwconv_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                              const float *__restrict__ prescale, float *__restrict__ y, int B, int H, int W, int C,
+                              int k, int tile16) {
+  const int C4 = C >> 2, pad = k >> 1;
+  const long total = (long)B * H * W * C4;
+  GRID_STRIDE(i, total) {
+    const int c4 = (int)(i % C4);
+    long t = i / C4;
+    const int xx = (int)(t % W);
+    t /= W;
+    const int yy = (int)(t % H);
+    const int b = (int)(t / H);
+    f32x4 acc = bias ? reinterpret_cast<const f32x4 *>(bias)[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 ps = prescale ? reinterpret_cast<const f32x4 *>(prescale)[c4] : f32x4{1.f, 1.f, 1.f, 1.f};
+    for (int ky = 0; ky < k; ky++) {
+      const int sy = yy + ky - pad;
+      if (sy < 0 || sy >= H) continue;
+      for (int kx = 0; kx < k; kx++) {
+        const int sx = xx + kx - pad;
+        if (sx < 0 || sx >= W) continue;
+        f32x4 v = reinterpret_cast<const f32x4 *>(x + fmap_row(b, sy, sx, H, W, tile16) * C)[c4];
+        if (prescale) v *= ps;
+        const f32x4 wv = reinterpret_cast<const f32x4 *>(w + (long)(ky * k + kx) * C)[c4];
+        acc += v * wv;
+      }
+    }
+    reinterpret_cast<f32x4 *>(y + fmap_row(b, yy, xx, H, W, tile16) * C)[c4] = acc;
+  }
+}
+
+extern "C" int sgic_dwconv_nhwc(const float *d_x, const float *d_w, const float *d_bias, const float *d_prescale,
+                                float *d_y, int B, int H, int W, int C, int k, int tile16, sgic_stream_t stream) {
+  SGIC_REQUIRE(d_x && d_w && d_y && d_x != d_y && B > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && (k & 1) == 1, "args");
+  SGIC_REQUIRE(!tile16 || (H % 16 == 0 && W % 16 == 0), "tile-major layout needs H,W multiples of 16");
+  const long total = (long)B * H * W * (C / 4);
+  dwconv_kernel<<<ew_grid(total), 256, 0, to_stream(stream)>>>(d_x, d_w, d_bias, d_prescale, d_y, B, H, W, C, k, tile16);
+  return sgic::check_launch("dwconv_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// im2col for the 2x2 stride-2 conv of feat_out (codec_sq_fixbpp.py:90): NHWC (TM16 or plain) in,
+// out[(b, y/2, x/2) plain][(ky*2+kx)*C + c]
+// ------------------------------------------------------------------------------------------------
+__global__ void im2col_2x2_kernel(const float *__restrict__ x, int B, int H, int W, int C, int tile16,
+                                  float *__restrict__ out) {
+  const int C4 = C >> 2, OH = H >> 1, OW = W >> 1;
+  const long total = (long)B * OH * OW * 4 * C4;
+  GRID_STRIDE(i, total) {
+    const int c4 = (int)(i % C4);
+    long t = i / C4;
+    const int kk = (int)(t & 3);
+    t >>= 2;
+    const int ox = (int)(t % OW);
+    t /= OW;
+    const int oy = (int)(t % OH);
+    const int b = (int)(t / OH);
+    const f32x4 v = reinterpret_cast<const f32x4 *>(x + fmap_row(b, oy * 2 + (kk >> 1), ox * 2 + (kk & 1), H, W, tile16) * C)[c4];
+    reinterpret_cast<f32x4 *>(out + ((((long)b * OH + oy) * OW + ox) * 4 + kk) * C)[c4] = v;
+  }
+}
+
+extern "C" int sgic_im2col_2x2(const float *d_x, int B, int H, int W, int C, int tile16, float *d_out,
+                               sgic_stream_t stream) {
+  SGIC_REQUIRE(d_x && d_out && B > 0 && H > 0 && W > 0 && (H & 1) == 0 && (W & 1) == 0 && (C & 3) == 0, "args");
+  const long total = (long)B * (H / 2) * (W / 2) * C;
+  im2col_2x2_kernel<<<ew_grid(total), 256, 0, to_stream(stream)>>>(d_x, B, H, W, C, tile16, d_out);
+  return sgic::check_launch("im2col_2x2_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// ConvFFN3 gate: out[m,c] = LeakyReLU_0.1(x[m,c]) + LeakyReLU_0.01(x[m,C2+c])   (blocks/dcvc.py:50-53)
+// ------------------------------------------------------------------------------------------------
+__global__ void gated_lrelu_kernel(const float *__restrict__ x, float *__restrict__ out, long M, int C2) {
+  const int C4 = C2 >> 2;
+  const long total = M * C4;
+  GRID_STRIDE(i, total) {
+    const int c4 = (int)(i % C4);
+    const long m = i / C4;
+    const f32x4 a = reinterpret_cast<const f32x4 *>(x + m * 2 * C2)[c4];
+    const f32x4 b = reinterpret_cast<const f32x4 *>(x + m * 2 * C2 + C2)[c4];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; e++) o[e] = (a[e] >= 0.f ? a[e] : 0.1f * a[e]) + (b[e] >= 0.f ? b[e] : 0.01f * b[e]);
+    reinterpret_cast<f32x4 *>(out + m * C2)[c4] = o;
+  }
+}
+
+extern "C" int sgic_gated_lrelu(const float *d_x, float *d_out, int M, int C2, sgic_stream_t stream) {
+  SGIC_REQUIRE(d_x && d_out && M > 0 && C2 > 0 && (C2 & 3) == 0, "args");
+  gated_lrelu_kernel<<<ew_grid((long)M * C2 / 4), 256, 0, to_stream(stream)>>>(d_x, d_out, M, C2);
+  return sgic::check_launch("gated_lrelu_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Broadcast column ops on (M, C) rows, vec has `vrows` rows of C and row m uses vec[m % vrows]:
+//   mode 0: y = x * v          (enc_q / dec_q scaling, models/sq_bottleneck.py:111,117; y_hat*q_step)
+//   mode 1: y = x / max(v,0.5) (y / clamp_min(q_step, 0.5), entropy/compression_model.py:325-326)
+// ------------------------------------------------------------------------------------------------
+__global__ void colop_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ v, int ldv, int vrows,
+                             float *__restrict__ y, int ldy, long M, int C, int mode) {
+  const int C4 = C >> 2;
+  const long total = M * C4;
+  GRID_STRIDE(i, total) {
+    const int c4 = (int)(i % C4);
+    const long m = i / C4;
+    const f32x4 a = reinterpret_cast<const f32x4 *>(x + m * ldx)[c4];
+    const f32x4 b = reinterpret_cast<const f32x4 *>(v + (m % vrows) * ldv)[c4];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; e++) o[e] = mode == 0 ? a[e] * b[e] : a[e] / fmaxf(b[e], 0.5f);
+    reinterpret_cast<f32x4 *>(y + m * ldy)[c4] = o;
+  }
+}
+
+extern "C" int sgic_colop(const float *d_x, int ldx, const float *d_v, int ldv, int vrows, float *d_y, int ldy, int M,
+                          int C, int mode, sgic_stream_t stream) {
+  SGIC_REQUIRE(d_x && d_v && d_y && M > 0 && C > 0 && (C & 3) == 0 && vrows > 0 && (mode == 0 || mode == 1), "args");
+  SGIC_REQUIRE((ldx & 3) == 0 && (ldv & 3) == 0 && (ldy & 3) == 0, "leading dims multiple of 4");
+  colop_kernel<<<ew_grid((long)M * C / 4), 256, 0, to_stream(stream)>>>(d_x, ldx, d_v, ldv, vrows, d_y, ldy, M, C, mode);
+  return sgic::check_launch("colop_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// "fake 2-D" reshape of the latent tokens (codec_sq_fixbpp.py:175-177): the (T, D) row-major block of
+// each sequence is REINTERPRETED as (D, T); conv_out then contracts over the first axis.  We emit
+// out[n][t][c] = in[n][c*T + t] so that conv_out is a plain GEMM over c.
+// ------------------------------------------------------------------------------------------------
+__global__ void fake2d_transpose_kernel(const float *__restrict__ in, long in_seq_stride, float *__restrict__ out, int N,
+                                        int T, int D) {
+  const long total = (long)N * T * D;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % D);
+    const long r = i / D;
+    const int t = (int)(r % T);
+    const int n = (int)(r / T);
+    out[i] = in[(long)n * in_seq_stride + (long)c * T + t];
+  }
+}
+
+extern "C" int sgic_fake2d_transpose(const float *d_in, long in_seq_stride, float *d_out, int N, int T, int D,
+                                     sgic_stream_t stream) {
+  SGIC_REQUIRE(d_in && d_out && N > 0 && T > 0 && D > 0, "args");
+  fake2d_transpose_kernel<<<ew_grid((long)N * T * D), 256, 0, to_stream(stream)>>>(d_in, in_seq_stride, d_out, N, T, D);
+  return sgic::check_launch("fake2d_transpose_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// TiTok VQ nearest code with l2-normalised tokens and codebook (titok/quantizer.py:46-61):
+// d = |z|^2 + |e|^2 - 2 z.e ; argmin (first minimum).  One wave per token, codes strided over lanes.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vq_argmin_kernel(const float *__restrict__ z, int ldz, const float *__restrict__ cb,
+                                                        int ncodes, int dim, int M, int l2norm, int *__restrict__ idx) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  float zv[16];
+  float zn = 0.f;
+  for (int d = 0; d < dim; d++) {
+    zv[d] = z[(long)m * ldz + d];
+    zn += zv[d] * zv[d];
+  }
+  if (l2norm) {
+    const float inv = 1.0f / fmaxf(sqrtf(zn), 1e-12f);
+    zn = 0.f;
+    for (int d = 0; d < dim; d++) {
+      zv[d] *= inv;
+      zn += zv[d] * zv[d];
+    }
+  }
+  float best = INFINITY;
+  int besti = 0x7fffffff;
+  for (int c = lane; c < ncodes; c += 64) {
+    float ev[16];
+    float en = 0.f;
+    for (int d = 0; d < dim; d++) {
+      ev[d] = cb[(long)c * dim + d];
+      en += ev[d] * ev[d];
+    }
+    if (l2norm) {
+      const float inv = 1.0f / fmaxf(sqrtf(en), 1e-12f);
+      en = 0.f;
+      for (int d = 0; d < dim; d++) {
+        ev[d] *= inv;
+        en += ev[d] * ev[d];
+      }
+    }
+    float dot = 0.f;
+    for (int d = 0; d < dim; d++) dot += zv[d] * ev[d];
+    const float dist = zn + en - 2.0f * dot;
+    if (dist < best) best = dist, besti = c;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o);
+    const int oi = __shfl_xor(besti, o);
+    if (ob < best || (ob == best && oi < besti)) best = ob, besti = oi;
+  }
+  if (lane == 0) idx[m] = besti;
+}
+
+extern "C" int sgic_vq_argmin(const float *d_z, int ldz, const float *d_codebook, int ncodes, int dim, int M, int l2norm,
+                              int32_t *d_idx, sgic_stream_t stream) {
+  SGIC_REQUIRE(d_z && d_codebook && d_idx && M > 0 && ncodes > 0 && dim > 0 && dim <= 16 && ldz >= dim, "args");
+  vq_argmin_kernel<<<cdiv(M, 4), 256, 0, to_stream(stream)>>>(d_z, ldz, d_codebook, ncodes, dim, M, l2norm, d_idx);
+  return sgic::check_launch("vq_argmin_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// CLIP preprocessing, bit-exact with ToPILImage -> PIL bicubic(antialias) resize -> center crop ->
+// ToTensor -> Normalize (compress.py:70-71 + open_clip's image transform).
+//   k1: fp32 [-1,1] CHW (row stride ldx) -> u8 = trunc((clamp(x)*0.5+0.5)*255)
+//   k2: horizontal pass u8 -> u8 (Pillow ImagingResampleHorizontal_8bpc, 22-bit fixed-point coeffs)
+//   k3: vertical pass + crop + (v/255 - mean)/std -> fp32 (3, S, S)
+// Coefficient tables (bounds, ints) are built on the host in double precision like Pillow does.
+// ------------------------------------------------------------------------------------------------
+__global__ void to_u8_kernel(const float *__restrict__ x, long img_stride, long ch_stride, int ldx, int B, int H, int W,
+                             uint8_t *__restrict__ out) {
+  const long total = (long)B * 3 * H * W;
+  GRID_STRIDE(i, total) {
+    const int xx = (int)(i % W);
+    long t = i / W;
+    const int yy = (int)(t % H);
+    t /= H;
+    const int c = (int)(t % 3);
+    const int b = (int)(t / 3);
+    float v = x[b * img_stride + c * ch_stride + (long)yy * ldx + xx];
+    v = fminf(fmaxf(v, -1.f), 1.f);
+    v = (v * 0.5f + 0.5f) * 255.f;
+    out[i] = (uint8_t)v;  // .byte() truncates
+  }
+}
+
+__global__ void resize_h_kernel(const uint8_t *__restrict__ in, int B3, int H, int W, int OW, const int *__restrict__ bounds,
+                                const int *__restrict__ kk, int ksize, uint8_t *__restrict__ out) {
+  const long total = (long)B3 * H * OW;
+  GRID_STRIDE(i, total) {
+    const int xx = (int)(i % OW);
+    const long row = i / OW;  // (b*3+c)*H + y
+    const int xmin = bounds[2 * xx], cnt = bounds[2 * xx + 1];
+    int ss = 1 << 21;
+    const uint8_t *p = in + row * W + xmin;
+    const int *k = kk + xx * ksize;
+    for (int x = 0; x < cnt; x++) ss += (int)p[x] * k[x];
+    ss >>= 22;
+    out[i] = (uint8_t)(ss < 0 ? 0 : (ss > 255 ? 255 : ss));
+  }
+}
+
+__global__ void resize_v_crop_norm_kernel(const uint8_t *__restrict__ in, int B, int H, int OW, int S, int top, int left,
+                                          const int *__restrict__ bounds, const int *__restrict__ kk, int ksize,
+                                          float m0, float m1, float m2, float s0, float s1, float s2,
+                                          float *__restrict__ out) {
+  const long total = (long)B * 3 * S * S;
+  GRID_STRIDE(i, total) {
+    const int xx = (int)(i % S);
+    long t = i / S;
+    const int yy = (int)(t % S);
+    t /= S;
+    const int c = (int)(t % 3);
+    const int b = (int)(t / 3);
+    const int oy = yy + top, ox = xx + left;
+    const int ymin = bounds[2 * oy], cnt = bounds[2 * oy + 1];
+    const int *k = kk + oy * ksize;
+    const uint8_t *p = in + ((long)(b * 3 + c) * H + ymin) * OW + ox;
+    int ss = 1 << 21;
+    for (int y = 0; y < cnt; y++) ss += (int)p[(long)y * OW] * k[y];
+    ss >>= 22;
+    const int u = ss < 0 ? 0 : (ss > 255 ? 255 : ss);
+    const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+    out[i] = ((float)u / 255.0f - mean) / sd;
+  }
+}
+
+extern "C" int sgic_clip_preprocess(const float *d_x, long img_stride, long ch_stride, int ldx, int B, int H, int W,
+                                    int OH, int OW, int S, int top, int left, const int32_t *d_bounds_h,
+                                    const int32_t *d_kk_h, int ksize_h, const int32_t *d_bounds_v, const int32_t *d_kk_v,
+                                    int ksize_v, const float *mean3, const float *std3, uint8_t *d_tmp_u8,
+                                    uint8_t *d_tmp_h, float *d_out, sgic_stream_t stream) {
+  SGIC_REQUIRE(d_x && d_tmp_u8 && d_tmp_h && d_out && mean3 && std3 && B > 0 && H > 0 && W > 0 && S > 0, "args");
+  SGIC_REQUIRE(top >= 0 && left >= 0 && top + S <= OH && left + S <= OW, "crop window");
+  SGIC_REQUIRE(d_bounds_h && d_kk_h && d_bounds_v && d_kk_v, "coefficient tables");
+  hipStream_t st = to_stream(stream);
+  to_u8_kernel<<<ew_grid((long)B * 3 * H * W), 256, 0, st>>>(d_x, img_stride, ch_stride, ldx, B, H, W, d_tmp_u8);
+  resize_h_kernel<<<ew_grid((long)B * 3 * H * OW), 256, 0, st>>>(d_tmp_u8, B * 3, H, W, OW, d_bounds_h, d_kk_h, ksize_h,
+                                                                d_tmp_h);
+  resize_v_crop_norm_kernel<<<ew_grid((long)B * 3 * S * S), 256, 0, st>>>(d_tmp_h, B, H, OW, S, top, left, d_bounds_v,
+                                                                          d_kk_v, ksize_v, mean3[0], mean3[1], mean3[2],
+                                                                          std3[0], std3[1], std3[2], d_out);
+  return sgic::check_launch("clip_preprocess");
+}
+
+// ------------------------------------------------------------------------------------------------
+// CLIP head: unit-normalise each row and u8-quantise  q = clip(rint((z*0.5+0.5)*255), 0, 255)
+// (compress.py:73,77)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2norm_u8_kernel(const float *__restrict__ x, int ldx, int M, int D,
+                                                        float *__restrict__ unit, uint8_t *__restrict__ q) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  float s = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    const float v = x[(long)m * ldx + d];
+    s += v * v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float nrm = sqrtf(s);
+  for (int d = lane; d < D; d += 64) {
+    const float u = x[(long)m * ldx + d] / nrm;
+    unit[(long)m * D + d] = u;
+    const float r = rintf((u * 0.5f + 0.5f) * 255.0f);
+    q[(long)m * D + d] = (uint8_t)fminf(fmaxf(r, 0.f), 255.f);
+  }
+}
+
+extern "C" int sgic_l2norm_u8(const float *d_x, int ldx, int M, int D, float *d_unit, uint8_t *d_q, sgic_stream_t stream) {
+  SGIC_REQUIRE(d_x && d_unit && d_q && M > 0 && D > 0 && ldx >= D, "args");
+  l2norm_u8_kernel<<<cdiv(M, 4), 256, 0, to_stream(stream)>>>(d_x, ldx, M, D, d_unit, d_q);
+  return sgic::check_launch("l2norm_u8_kernel");
+}
