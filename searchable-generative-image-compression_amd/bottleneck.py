@@ -1,0 +1,169 @@
+"""Compressive bottleneck on MI355X: analysis transform, 4-step spatial-prior entropy model and the
+batched rANS coder (reference: models/sq_bottleneck.py:55-199, entropy/compression_model.py:224-418,
+entropy/entropy_models.py:252-374, blocks/dcvc.py:14-66).
+
+All images of a batch are coded concurrently: the prior network runs batched, the fused
+quantise+index kernel writes (B, 4, 16, h, w) int16 symbols/indexes straight into the layout the rANS
+kernel consumes (one workgroup per image), and nothing touches the host until the finished streams are
+copied out.  The input-independent prior `y_prior_fusion(q_prior)` is computed once per (B, h, w)."""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from .config import CodecConfig
+from .entropy.MLCodec_rans import _Tables
+
+
+def _dev(t, device):
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class Dcb4W:
+    """DepthConvBlock4 (blocks/dcvc.py:57-66)"""
+
+    def __init__(self, sd, p, device):
+        q = f"{p}.block.0"
+        cin = sd[f"{q}.conv1.0.weight"].shape[0]
+        cout = sd[f"{q}.conv2.weight"].shape[0]
+        self.cin, self.cout = cin, cout
+        self.c1w, self.c1b = _dev(sd[f"{q}.conv1.0.weight"].reshape(cin, cin), device), _dev(sd[f"{q}.conv1.0.bias"], device)
+        self.dw = _dev(sd[f"{q}.depth_conv.weight"].reshape(cin, 9).t(), device)
+        self.db = _dev(sd[f"{q}.depth_conv.bias"], device)
+        self.c2w, self.c2b = _dev(sd[f"{q}.conv2.weight"].reshape(cout, cin), device), _dev(sd[f"{q}.conv2.bias"], device)
+        self.aw = self.ab = None
+        if f"{q}.adaptor.weight" in sd:
+            self.aw, self.ab = _dev(sd[f"{q}.adaptor.weight"].reshape(cout, cin), device), _dev(sd[f"{q}.adaptor.bias"], device)
+        q = f"{p}.block.1"
+        self.fw, self.fb = _dev(sd[f"{q}.conv.weight"].reshape(4 * cout, cout), device), _dev(sd[f"{q}.conv.bias"], device)
+        self.ow, self.ob = _dev(sd[f"{q}.conv_out.weight"].reshape(cout, 2 * cout), device), _dev(sd[f"{q}.conv_out.bias"], device)
+
+
+def dcb4_forward(x, w: Dcb4W, B, H, W):
+    """x [(B*H*W), cin] plain NHWC -> [(B*H*W), cout]"""
+    idn = ops.gemm(x, w.aw, w.ab) if w.aw is not None else x
+    t = ops.gemm(x, w.c1w, w.c1b, act=ops.ACT_LRELU)
+    t = ops.dwconv(t, w.dw, w.db, None, B, H, W, 3, tile16=False)
+    x = ops.gemm(t, w.c2w, w.c2b, residual=idn)
+    t = ops.gemm(x, w.fw, w.fb)
+    g = ops.gated_lrelu(t)
+    return ops.gemm(g, w.ow, w.ob, residual=x)
+
+
+def gaussian_cdf_table():
+    """GaussianEncoder.update (entropy/entropy_models.py:313-353) with the reference's own recipe: torch-CPU
+    fp32 Normal.cdf for the PMFs, then the native quantiser (here: libsgic's sgic_pmf_to_quantized_cdf).
+    Host-side, once per process.  Returns (cdf (256,103) int32, cdf_length, offset) numpy arrays."""
+    from .entropy.MLCodec_CXX import pmf_to_quantized_cdf
+    scale_table = torch.exp(torch.linspace(math.log(0.11), math.log(64.0), 256))
+    pmf_center = torch.zeros_like(scale_table) + 50
+    dist = torch.distributions.normal.Normal(torch.zeros_like(scale_table), scale_table)
+    for i in range(50, 1, -1):
+        probs = dist.cdf(torch.zeros_like(pmf_center) + i)
+        pmf_center = torch.where(probs > 0.9999, torch.zeros_like(pmf_center) + i, pmf_center)
+    pmf_center = pmf_center.int()
+    pmf_length = 2 * pmf_center + 1
+    max_length = int(pmf_length.max())
+    samples = (torch.arange(max_length) - pmf_center[:, None]).float()
+    scales = torch.zeros_like(samples) + scale_table[:, None]
+    dist = torch.distributions.normal.Normal(torch.zeros_like(scales), scales)
+    upper, lower = dist.cdf(samples + 0.5), dist.cdf(samples - 0.5)
+    pmf = upper - lower
+    tail = 2 * lower[:, :1]
+    cdf = np.zeros((256, max_length + 2), dtype=np.int32)
+    for i in range(256):
+        prob = torch.cat((pmf[i, :pmf_length[i]], tail[i]), dim=0)
+        c = pmf_to_quantized_cdf(prob.tolist(), 16)
+        cdf[i, :len(c)] = c
+    return cdf, (pmf_length + 2).numpy().astype(np.int32), (-pmf_center).numpy().astype(np.int32)
+
+
+class BottleneckHIP:
+    def __init__(self, sd, cfg: CodecConfig, device, p="hybrid_codec.quantize_feat"):
+        self.cfg, self.device = cfg, device
+        Fd, Q = cfg.feat_dim, cfg.embed_dim
+        self.Q = Q
+        self.force_zero_thres = cfg.force_zero_thres
+        self.enc_q = _dev(sd[f"{p}.enc_q"][0].reshape(1, Fd), device)
+        self.dec_q = _dev(sd[f"{p}.dec_q"][0].reshape(1, Fd), device)
+        self.prior_vec = _dev(sd[f"{p}.factorized_prior_vec"][0].reshape(1, Q), device)
+        D = lambda k: Dcb4W(sd, f"{p}.{k}", device)
+        self.enc0 = [D("enc_trans_0.0"), D("enc_trans_0.1")]
+        self.enc1 = [D("enc_trans_1.0"), D("enc_trans_1.1")]
+        self.fusion = [D("y_prior_fusion.0"), D("y_prior_fusion.1")]
+        self.red_w = _dev(sd[f"{p}.y_spatial_prior_reduction.weight"].reshape(Q, 3 * Q), device)
+        self.red_b = _dev(sd[f"{p}.y_spatial_prior_reduction.bias"], device)
+        self.adaptor = [None] + [D(f"y_spatial_prior_adaptor_{k}") for k in (1, 2, 3)]
+        self.prior = [D(f"y_spatial_prior.{k}") for k in range(3)]
+        self._prior_cache = {}
+        self.tables = None
+        self.group = None
+
+    def update(self, force=False):
+        """CompressionModel.update (entropy/compression_model.py:169-171): build + register the CDF group"""
+        if self.tables is not None and not force:
+            return
+        self.tables = _Tables()
+        self.cdf_info = gaussian_cdf_table()
+        self.group = self.tables.add(*self.cdf_info)
+
+    def _prior(self, B, H, W):
+        """params = y_prior_fusion(q_prior) and its 1x1 reduction, replicated over the batch"""
+        key = (B, H, W)
+        if key not in self._prior_cache:
+            hw, Q = H * W, self.Q
+            q = self.prior_vec.expand(hw, Q).contiguous()
+            params = dcb4_forward(dcb4_forward(q, self.fusion[0], 1, H, W), self.fusion[1], 1, H, W)   # [hw, 3Q]
+            common = ops.gemm(params, self.red_w, self.red_b)                                           # [hw, Q]
+            paramsB = torch.empty(B * hw, 3 * Q, device=self.device)
+            ops.add_rows_bcast(params, 0, None, paramsB, hw, B, hw)
+            commonB = torch.empty(B * hw, Q, device=self.device)
+            ops.add_rows_bcast(common, 0, None, commonB, hw, B, hw)
+            self._prior_cache[key] = (paramsB, commonB)
+        return self._prior_cache[key]
+
+    def analysis(self, h, B, H, W):
+        """get_qp + encode (models/sq_bottleneck.py:102-113): h [(B*H*W), Fd] -> y [(B*H*W), Q]"""
+        y = dcb4_forward(dcb4_forward(h, self.enc0[0], B, H, W), self.enc0[1], B, H, W)
+        y = ops.colop(y, self.enc_q, 0)
+        return dcb4_forward(dcb4_forward(y, self.enc1[0], B, H, W), self.enc1[1], B, H, W)
+
+    def quantise(self, y, B, H, W):
+        """forward_four_part_prior(write=True) + build_indexes (compression_model.py:303-366,
+        entropy_models.py:355-362): -> sym, idx (B, 4, Q/4, H, W) int16 on device, ctx buffer"""
+        Q, hw = self.Q, H * W
+        paramsB, commonB = self._prior(B, H, W)
+        yq = ops.colop(y, paramsB[:, 0:Q], 1)                       # y / clamp_min(q_step, 0.5)
+        ctx = torch.zeros(B * hw, 2 * Q, device=self.device)        # [y_hat_so_far | reduced params]
+        ops.add_rows_bcast(commonB, hw, None, ctx[:, Q:], hw, B, hw)
+        sym = torch.empty(B, 4, Q // 4, H, W, dtype=torch.int16, device=self.device)
+        idx = torch.empty_like(sym)
+        thr = self.force_zero_thres
+        ops.quant_step(yq, paramsB[:, Q:2 * Q], paramsB[:, 2 * Q:], 3 * Q, ctx, 2 * Q, B, H, W, Q, 0, thr, sym, idx)
+        for k in (1, 2, 3):
+            t = dcb4_forward(ctx, self.adaptor[k], B, H, W)
+            for w in self.prior:
+                t = dcb4_forward(t, w, B, H, W)
+            ops.quant_step(yq, t[:, 0:Q], t[:, Q:], 2 * Q, ctx, 2 * Q, B, H, W, Q, k, thr, sym, idx)
+        return sym, idx, ctx, paramsB
+
+    def compress(self, h, B, H, W):
+        """Compressive_bottleneck_varbpp_type2.compress for a whole batch (models/sq_bottleneck.py:159-182).
+        Returns device tensors (out (B,cap) u8, meta (3,B) i32 = off/len/err) -- one rANS stream per image."""
+        if self.tables is None:
+            raise RuntimeError("call update(force=True) first (compress.py:239)")
+        y = self.analysis(h, B, H, W)
+        sym, idx, _, _ = self.quantise(y, B, H, W)
+        n = 4 * (self.Q // 4) * H * W
+        out, meta = ops.rans_encode_batch(self.tables.handles[self.group], sym, idx, B, n)
+        return out, meta, sym, idx
+
+    @staticmethod
+    def streams_to_host(out, meta):
+        """one D2H copy of the slots + (off, len, err); returns list[bytes]"""
+        h_meta = meta.cpu().numpy()
+        if int(np.abs(h_meta[2]).sum()) != 0:
+            raise RuntimeError(f"rANS encode error codes {h_meta[2].tolist()} (slot too small or bad index)")
+        h_out = out.cpu().numpy()
+        return [h_out[b, h_meta[0, b]:h_meta[0, b] + h_meta[1, b]].tobytes() for b in range(out.shape[0])]

@@ -1,0 +1,126 @@
+"""Codec facade: the drop-in for `models.codec_sq_fixbpp.Codec` on the compress path
+(reference: models/codec_sq_fixbpp.py:442-508,841-878) plus `ClipCodec` (compress.py:58-86).
+
+`Codec.encode_only(x)` keeps the reference contract (one padded image in, the enc_result dict out);
+`Codec.encode_batch(x)` is the MI355X-native entry: B images per call, everything device-resident until
+the finished byte strings are copied out once."""
+import numpy as np
+import torch
+
+from . import ops
+from .bottleneck import BottleneckHIP
+from .clip import ClipHIP
+from .config import CLIP_B32, LARGE, ClipConfig, CodecConfig
+from .encoder import HybridEncoderHIP
+from .zstd import Compressor
+
+
+class _QuantizeFeatProxy:
+    """`model.hybrid_codec.quantize_feat.force_zero_thres = 0.12; .update(force=True)` (compress.py:238-239)"""
+
+    def __init__(self, bott):
+        self._b = bott
+
+    @property
+    def force_zero_thres(self):
+        return self._b.force_zero_thres
+
+    @force_zero_thres.setter
+    def force_zero_thres(self, v):
+        self._b.force_zero_thres = v
+
+    def update(self, force=False):
+        self._b.update(force=force)
+
+
+class _HybridCodecProxy:
+    def __init__(self, bott):
+        self.quantize_feat = _QuantizeFeatProxy(bott)
+
+
+class Codec:
+    def __init__(self, state_dict, cfg: CodecConfig = LARGE, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("sgic_amd.Codec needs an MI355X GPU (HIP-only hot path, no CPU fallback)")
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.encoder = HybridEncoderHIP(state_dict, cfg, self.device)
+        self.bottleneck = BottleneckHIP(state_dict, cfg, self.device)
+        self.codebook = state_dict["hybrid_codec.quantize.embedding.weight"].to(self.device).float().contiguous()
+        self.hybrid_codec = _HybridCodecProxy(self.bottleneck)
+
+    def to(self, device):
+        return self
+
+    def eval(self):
+        return self
+
+    def encode_device(self, x):
+        """x (B,3,H,W) on device, in [-1,1], H,W multiples of 256 -> device-side results"""
+        cfg = self.cfg
+        B, _, H, W = x.shape
+        assert H % cfg.crop_size == 0 and W % cfg.crop_size == 0, "pad to a multiple of 256 first (compress.py:258)"
+        z, h, (nH, nW) = self.encoder.forward(x)
+        vq = ops.vq_argmin(z, self.codebook, l2norm=True)                  # [(B*nH*nW*T)] int32
+        ntok = cfg.num_latent_tokens * nH * nW
+        zs = ops.pack12_batch(vq, B, ntok)
+        hh, ww = H // (2 * cfg.patch_size), W // (2 * cfg.patch_size)
+        out, meta, sym, idx = self.bottleneck.compress(h, B, hh, ww)
+        return dict(z=z, h=h, vq=vq, zs=zs, hs=out, hmeta=meta, sym=sym, idx=idx, stack=(nH, nW), feat_hw=(hh, ww), ntok=ntok)
+
+    def encode_batch(self, x):
+        """-> list of B enc_result dicts (the reference's encode_only contract, one per image)"""
+        cfg = self.cfg
+        B, _, H, W = x.shape
+        r = self.encode_device(x)
+        h_streams = BottleneckHIP.streams_to_host(r["hs"], r["hmeta"])
+        zs = r["zs"].cpu().numpy()
+        nH, nW = r["stack"]
+        hh, ww = r["feat_hw"]
+        res = []
+        for b in range(B):
+            res.append({
+                "z_bit_stream": zs[b].tobytes(),
+                "h_bit_stream": h_streams[b],
+                "img_shape": (H, W),
+                "feat_shape": torch.Size([1, cfg.feat_dim, hh, ww]),
+                "stack_shape": (nH, nW),
+                "token_length": r["ntok"],
+                "z_indices_shape": torch.Size([nH * nW, cfg.token_size, 1, cfg.num_latent_tokens]),
+            })
+        return res
+
+    @torch.no_grad()
+    def encode_only(self, x):
+        """reference signature: x (1,3,256a,256b) in [-1,1] -> dict (codec_sq_fixbpp.py:849-878)"""
+        assert x.shape[0] == 1
+        return self.encode_batch(x.to(self.device).float().contiguous())[0]
+
+
+class ClipCodec:
+    """compress.py:58-86"""
+
+    def __init__(self, state_dict, cfg: ClipConfig = CLIP_B32, device="cuda:0", model_name="ViT-B-32",
+                 pretrained="laion2b_s34b_b79k"):
+        self.device = torch.device(device)
+        self.model = ClipHIP(state_dict, cfg, self.device)
+        self.model_name = f"{model_name}:{pretrained}"
+        self.zctx = Compressor(level=19)
+
+    def image_to_unit_vec(self, img_chw):
+        unit, _ = self.model.encode(img_chw.to(self.device).float().contiguous()[None])
+        return unit[0].cpu().numpy().astype("float32")
+
+    def batch_to_codes(self, x, H=None, W=None):
+        """(B,3,Hp,Wp) device batch -> (unit (B,D) device, u8 (B,D) device)"""
+        return self.model.encode(x, H, W)
+
+    def meta(self, dim):
+        return {"model_id": self.model_name, "dim": int(dim), "quant": "u8_symmetric_-1_1", "codec": "zstd", "zstd_level": 19}
+
+    def quantize_u8_and_compress(self, z_unit: np.ndarray):
+        q = np.clip(np.round((z_unit * 0.5 + 0.5) * 255.0), 0, 255).astype(np.uint8)
+        return self.zctx.compress(q.tobytes()), self.meta(z_unit.shape[0])
+
+    def compress_codes(self, q_u8_row: np.ndarray):
+        return self.zctx.compress(q_u8_row.tobytes())

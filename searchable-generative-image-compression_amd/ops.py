@@ -178,3 +178,36 @@ def l2norm_u8(x):
     q = torch.empty(M, D, device=x.device, dtype=torch.uint8)
     call("sgic_l2norm_u8", _p(x), ldx, M, D, _p(unit), _p(q))
     return unit, q
+
+
+# ---- entropy-side kernels (device-resident batch API) ----
+def quant_step(y, scales, means, ld_sm, yhat, ld_yhat, B, H, W, C, k, thr, sym, idx):
+    call("sgic_quant_step", _p(y), _p(scales), _p(means), ld_sm, _p(yhat), ld_yhat, B, H, W, C, k,
+         float(-1.0 if thr is None else thr), _p(sym), _p(idx))
+
+
+def index_step(scales, ld_sm, B, H, W, C, k, thr, idx):
+    call("sgic_index_step", _p(scales), ld_sm, B, H, W, C, k, float(-1.0 if thr is None else thr), _p(idx))
+
+
+def dequant_step(sym, means, ld_sm, yhat, ld_yhat, B, H, W, C, k):
+    call("sgic_dequant_step", _p(sym), _p(means), ld_sm, _p(yhat), ld_yhat, B, H, W, C, k)
+
+
+def rans_encode_batch(table, sym, idx, B, n, cap=None):
+    """-> (out (B,cap) u8, off (B,) i32, len (B,) i32, err (B,) i32); streams are end-aligned in their slot"""
+    if cap is None:
+        cap = 2 * n + 64
+    dev = sym.device
+    out = torch.empty(B, cap, dtype=torch.uint8, device=dev)
+    meta = torch.empty(3, B, dtype=torch.int32, device=dev)
+    call("sgic_rans_encode_batch", table, _p(sym), _p(idx), B, n, _p(out), cap, _p(meta[0]), _p(meta[1]), _p(meta[2]))
+    return out, meta
+
+
+def pack12_batch(idx_i32, B, n):
+    from ._lib import lib
+    nb = lib.sgic_pack12_size(n)
+    out = torch.empty(B, nb, dtype=torch.uint8, device=idx_i32.device)
+    call("sgic_pack12_batch", _p(idx_i32), B, n, _p(out))
+    return out
