@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Benchmark of the compress hot path: images/s end-to-end compress (hybrid encoder + entropy coding + CLIP)
+at 256x256, batch 32 per GPU (BASELINE.json configs[1]), synthetic images and synthetic weights of the
+exact production architecture (TiTok ViT-L hybrid encoder, 64-ch bottleneck, OpenCLIP ViT-B/32).
+
+A step = one batch of 32 device-resident fp32 images -> 32 x (z_bit_stream, h_bit_stream, zstd'd CLIP code)
+as host byte strings.  One process per GPU (torch.distributed / RCCL), images sharded across ranks with no
+data-path collective except the all-gather of the CLIP vectors (for the FAISS index).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+GFLOP_PER_IMAGE = 366.3        # compress at 256x256 (355.3 enc + 2.16 bottleneck + 8.8 CLIP + VQ)
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def cpu_baseline(sd, clip_sd, cfg, clip_cfg, n_images):
+    """The oracle (kind "port"): torch-CPU fp32 restatement + C rANS, B=1 loop like compress.py:248."""
+    from oracle import orc
+    from oracle import torch_ref as TR
+    from sgic_amd.data import synth_images
+    # threads actually usable: the cgroup/affinity share of this process, not the host's core count
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("SGIC_CPU_THREADS", "16"))))
+    torch.set_num_threads(cores)
+    t = np.load(os.path.join(ROOT, "tests", "golden", "cdf_table.npz"))
+    tab = orc.Table(t["cdf"], t["cdf_length"], t["offset"])
+    x = synth_images(n_images, 256, 256, seed=99)
+    pre = torch.randn(1, 3, 224, 224)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        done = 0
+        for b in range(n_images):
+            if b > 0 and time.perf_counter() - t0 > 25.0:   # bounded sample: ~10-30 s of CPU work
+                break
+            print(f"[cpu_baseline] image {b} t={time.perf_counter() - t0:.1f}s", file=sys.stderr, flush=True)
+            xb = x[b:b + 1]
+            z, h, _ = TR.encoder_forward(xb * 0.5 + 0.5, sd, cfg)
+            idx = TR.vq_indices(z, sd)
+            orc.pack12(idx.numpy().astype(np.int16))
+            y = TR.bottleneck_analysis(h, sd)
+            sym, ind, _, _ = TR.four_part_prior_write(y, sd, cfg.force_zero_thres)
+            orc.rans_encode(sym.numpy(), ind.numpy(), tab)
+            u8 = orc.resize_bicubic_u8((xb[0].clamp(-1, 1).mul(0.5).add(0.5)).mul(255).byte().numpy(), 224, 224)
+            TR.clip_tower(pre, clip_sd, clip_cfg)
+            done += 1
+        dt = time.perf_counter() - t0
+    n_images = done
+    return {"value": round(n_images / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n_images} images 256x256, B=1 loop, torch-CPU fp32 restatement + C rANS oracle (oracle/)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--small", action="store_true", help="debug: SMALL/TINY configs (not a valid bench)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=6)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", init_method="env://")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import sgic_amd  # noqa: F401
+    from sgic_amd import ops
+    from sgic_amd import weights as W
+    from sgic_amd.codec import ClipCodec, Codec
+    from sgic_amd.config import CLIP_B32, CLIP_TINY, LARGE, SMALL
+    from sgic_amd.data import synth_images
+
+    cfg, clip_cfg = (SMALL, CLIP_TINY) if args.small else (LARGE, CLIP_B32)
+    sd = W.synth_weights(W.encoder_spec(cfg) + W.codec_misc_spec(cfg) + W.bottleneck_spec(cfg), seed=1234)
+    clip_sd = W.synth_weights(W.clip_spec(clip_cfg), seed=4321)
+    codec = Codec(sd, cfg, dev)
+    codec.hybrid_codec.quantize_feat.force_zero_thres = 0.12
+    codec.hybrid_codec.quantize_feat.update(force=True)
+    clipc = ClipCodec(clip_sd, clip_cfg, dev)
+
+    B, S = args.batch, args.size
+    x = synth_images(B, S, S, seed=1000 + rank).to(dev)   # inputs resident in HBM before the timed region
+    gathered = torch.empty(world * B, clip_cfg.embed_dim, device=dev) if world > 1 else None
+
+    def step():
+        r = codec.encode_device(x)
+        unit, q = clipc.batch_to_codes(x)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, unit)   # CLIP vectors for the FAISS index (RCCL over xGMI)
+        h_streams = codec.bottleneck.streams_to_host(r["hs"], r["hmeta"])
+        zs = r["zs"].cpu().numpy()
+        qh = q.cpu().numpy()
+        clip_streams = [clipc.compress_codes(qh[b]) for b in range(B)]
+        return [(zs[b].tobytes(), h_streams[b], clip_streams[b]) for b in range(B)]
+
+    for _ in range(args.warmup):
+        out = step()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ops.PROFILE = []
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        gemm_flops = sum(p[0] for p in prof)
+        gemm_ms = sum(p[1].elapsed_time(p[2]) for p in prof)
+        n_launch = len(prof)
+        achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        total_bytes = sum(len(a) + len(b) + len(c) for a, b, c in out)
+        res = {
+            "metric": "images/sec end-to-end compress (enc+entropy+CLIP) at 256x256",
+            "value": round(world * B * args.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: batch={B} {S}x{S} encoder+entropy+CLIP compress per GPU, "
+                                   f"{'SMALL debug model' if args.small else 'TiTok ViT-L hybrid encoder + ViT-B/32 CLIP'}, synthetic weights",
+                       "global_batch": world * B, "bytes_per_image": round(total_bytes / B, 1)},
+            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": n_launch // max(1, args.steps),
+                         "avg_launch_us": round(gemm_ms * 1e3 / max(1, n_launch), 2),
+                         "gflop_per_launch": round(gemm_flops / max(1, n_launch) / 1e9, 3),
+                         "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 4),
+                         "end_to_end_frac": round(GFLOP_PER_IMAGE * B * args.steps / dt / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline and not args.small:
+            res["cpu_baseline"] = cpu_baseline(sd, clip_sd, cfg, clip_cfg, args.cpu_images)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -8,6 +8,10 @@ from ._lib import call, require_gpu
 
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_TANH, ACT_LRELU = 0, 1, 2, 3, 4
 
+# Optional live profiling of the dominant kernel (bench.py): when PROFILE is a list, every gemm() launch is
+# bracketed by HIP events on the launch stream and (flops, start, end) is appended.
+PROFILE = None
+
 
 def _rows(t):
     """a 2-D fp32 CUDA view whose last dim is contiguous -> (tensor, leading dimension)"""
@@ -49,8 +53,14 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(
         assert residual.shape[1] == N and residual.shape[0] >= M
     if bias is not None:
         assert bias.shape == (N,) and bias.is_contiguous()
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     call("sgic_gemm_f32", _p(a), lda, _p(w), ldw, _p(bias), _p(residual), ldr, _p(out), ldc, M, N, K, act,
          a_seg[0], a_seg[1], c_seg[0], c_seg[1])
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((2.0 * M * N * K, e0, e1))
     return out
 
 
