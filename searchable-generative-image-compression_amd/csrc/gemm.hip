@@ -17,6 +17,8 @@
 // 36 KB LDS and ~110 VGPRs per workgroup -> 2-3 workgroups per CU, so one workgroup's staging
 // overlaps another's MFMAs.  blockIdx is remapped (bijectively) so that the workgroups sharing an
 // XCD's L2 work on neighbouring tiles of the same A row-panels.
+#include <math.h>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -59,9 +61,21 @@ __device__ __forceinline__ f32x4 ld4_guard(const float *p, bool ok) {
   return ok ? *reinterpret_cast<const f32x4 *>(p) : z;
 }
 
+// WN = MFMA column blocks per wave: 2 -> workgroup tile 128x128, 1 -> 128x64 (finer tiles for GEMMs whose
+// 128x128 grid would leave CUs idle in the last wave of workgroups).
+//
+// Pipeline (one barrier per K-step, MFMA stream never waits on LDS or HBM in steady state):
+//   top of step kt : ds_write tile kt+1 (VGPR staging, loaded one step ago) into the OTHER LDS buffer,
+//                    issue the global loads of tile kt+2
+//   sub-steps 0..2 : MFMAs on the current buffer, fragments of sub-step s+1 prefetched (2 register sets)
+//   barrier        : tile kt+1 visible, nobody reads the current buffer any more
+//   sub-step 3     : prefetch sub-step 0 of tile kt+1 from the other buffer, then the last 16/8 MFMAs
+template <int WN, bool KTAIL>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float sA[BM * LDS_LD];
-  __shared__ __attribute__((aligned(16))) float sB[BN * LDS_LD];
+  constexpr int TBN = 64 * WN;          // workgroup tile N
+  constexpr int NB4 = TBN / 32;         // float4 staged per thread for the W tile (TBN rows x 8 chunks / 256)
+  __shared__ __attribute__((aligned(16))) float sA[2][BM * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float sB[2][TBN * LDS_LD];
 
   // ---- XCD-aware bijective remap: hardware deals consecutive block ids round-robin over 8 XCDs ----
   const int nwg = g.tiles_m * g.tiles_n;
@@ -71,77 +85,125 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
   }
   const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * BM, n0 = tn * TBN;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * (32 * WN);
 
-  // staging map: 128 rows x 8 float4 per tile = 1024 float4 -> 4 per thread per operand
-  // thread t handles rows (t>>3) + 32*i, i=0..3, chunk (t&7)
+  // staging map: rows (tid>>3) + 32*i, 16-byte chunk (tid&7) of the 32-float K slice
   const int srow = tid >> 3, schunk = tid & 7;
-  f32x4 ra[4], rb[4];
+  f32x4 ra[4], rb[NB4];
+  const float *aptr[4];
+  const float *wptr[NB4];
+  // Staging loads are UNCONDITIONAL (a guarded load compiles to a branch + drained wait per load):
+  // out-of-range rows are clamped to the last valid row -- they only feed accumulator rows/columns that the
+  // epilogue never stores -- and the K tail (only when K % 32 != 0) is clamped in address and zeroed by a
+  // select on the loaded value.
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int am = min(m0 + srow + 32 * i, g.M - 1);
+    const size_t arow = g.a_seg ? (size_t)(am / g.a_seg) * g.a_seg_stride + (am % g.a_seg) : (size_t)am;
+    aptr[i] = g.A + arow * g.lda;
+  }
+#pragma unroll
+  for (int i = 0; i < NB4; i++) {
+    const int wr = min(n0 + srow + 32 * i, g.N - 1);
+    wptr[i] = g.W + (size_t)wr * g.ldw;
+  }
 
+  // KTAIL = false (K % 32 == 0, every large GEMM of the model): plain loads whose results are first touched
+  // by the ds_write one K-step later, so their latency hides under a full MFMA phase.  KTAIL = true: the
+  // tail chunk is clamped in address and zeroed by a select (this consumes the load early -- slow path, only
+  // used for odd K such as the 12-wide decoder embedding).
   auto issue_loads = [&](int k0) {
-    const int kk = k0 + schunk * 4;
-    const bool kok = kk < g.K;  // K % 4 == 0 is required, so a chunk is all-in or all-out
+    if constexpr (!KTAIL) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int r = srow + 32 * i;
-      const int am = m0 + r;
-      const size_t arow = g.a_seg ? (size_t)(am / g.a_seg) * g.a_seg_stride + (am % g.a_seg) : (size_t)am;
-      ra[i] = ld4_guard(g.A + arow * g.lda + kk, kok && am < g.M);
-      rb[i] = ld4_guard(g.W + (size_t)(n0 + r) * g.ldw + kk, kok && (n0 + r) < g.N);
+      for (int i = 0; i < 4; i++) ra[i] = *reinterpret_cast<const f32x4 *>(aptr[i] + k0 + schunk * 4);
+#pragma unroll
+      for (int i = 0; i < NB4; i++) rb[i] = *reinterpret_cast<const f32x4 *>(wptr[i] + k0 + schunk * 4);
+    } else {
+      const int kk = k0 + schunk * 4;
+      const bool kok = kk < g.K;  // K % 4 == 0, so a chunk is all-in or all-out
+      const int kc = kok ? kk : g.K - 4;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(aptr[i] + kc);
+        ra[i] = kok ? v : z;
+      }
+#pragma unroll
+      for (int i = 0; i < NB4; i++) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(wptr[i] + kc);
+        rb[i] = kok ? v : z;
+      }
     }
   };
-  auto store_lds = [&]() {
+  auto store_lds = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int r = srow + 32 * i;
-      *reinterpret_cast<f32x4 *>(&sA[r * LDS_LD + schunk * 4]) = ra[i];
-      *reinterpret_cast<f32x4 *>(&sB[r * LDS_LD + schunk * 4]) = rb[i];
-    }
+    for (int i = 0; i < 4; i++) *reinterpret_cast<f32x4 *>(&sA[buf][(srow + 32 * i) * LDS_LD + schunk * 4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NB4; i++) *reinterpret_cast<f32x4 *>(&sB[buf][(srow + 32 * i) * LDS_LD + schunk * 4]) = rb[i];
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][WN];
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < WN; j++)
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
   const int lrow = lane & 31, lhalf = lane >> 5;
-  const float *pa0 = &sA[(wm + lrow) * LDS_LD + lhalf * 4];
-  const float *pa1 = pa0 + 32 * LDS_LD;
-  const float *pb0 = &sB[(wn + lrow) * LDS_LD + lhalf * 4];
-  const float *pb1 = pb0 + 32 * LDS_LD;
+  const int aoff = (wm + lrow) * LDS_LD + lhalf * 4;
+  const int boff = (wn + lrow) * LDS_LD + lhalf * 4;
+
+  struct Frag {
+    f32x4 a[2], b[WN];
+  };
+  auto read_frag = [&](Frag &f, int buf, int s) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) f.a[i] = *reinterpret_cast<const f32x4 *>(&sA[buf][aoff + i * 32 * LDS_LD + s * 8]);
+#pragma unroll
+    for (int j = 0; j < WN; j++) f.b[j] = *reinterpret_cast<const f32x4 *>(&sB[buf][boff + j * 32 * LDS_LD + s * 8]);
+  };
+  auto mfma_frag = [&](const Frag &f) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < WN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][t], f.b[j][t], acc[i][j], 0, 0, 0);
+  };
 
   const int nk = (g.K + BK - 1) / BK;
+  Frag f0, f1;
   issue_loads(0);
+  store_lds(0);
+  if (nk > 1) issue_loads(BK);
+  __syncthreads();
+  read_frag(f0, 0, 0);
   for (int kt = 0; kt < nk; ++kt) {
-    store_lds();
-    __syncthreads();
-    if (kt + 1 < nk) issue_loads((kt + 1) * BK);  // in flight during the MFMA phase below
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const f32x4 a0 = *reinterpret_cast<const f32x4 *>(pa0 + s * 8);
-      const f32x4 a1 = *reinterpret_cast<const f32x4 *>(pa1 + s * 8);
-      const f32x4 b0 = *reinterpret_cast<const f32x4 *>(pb0 + s * 8);
-      const f32x4 b1 = *reinterpret_cast<const f32x4 *>(pb1 + s * 8);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b1[t], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b0[t], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc[1][1], 0, 0, 0);
-      }
+    const int cur = kt & 1, nxt = cur ^ 1;
+    if (kt + 1 < nk) {
+      store_lds(nxt);  // tile kt+1; buffer nxt was last read before the previous step's barrier
+      if (kt + 2 < nk) issue_loads((kt + 2) * BK);
     }
-    __syncthreads();
+    read_frag(f1, cur, 1);
+    mfma_frag(f0);
+    read_frag(f0, cur, 2);
+    mfma_frag(f1);
+    read_frag(f1, cur, 3);
+    mfma_frag(f0);
+    // one barrier per K-step: LDS traffic only (the staged global loads stay in flight across it)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nk) read_frag(f0, nxt, 0);
+    mfma_frag(f1);
   }
 
   // ---- epilogue: D[row = (e&3) + 8*(e>>2) + 4*lhalf][col = lrow] ----
 #pragma unroll
-  for (int j = 0; j < 2; j++) {
+  for (int j = 0; j < WN; j++) {
     const int n = n0 + wn + j * 32 + lrow;
     if (n >= g.N) continue;
     const float bv = g.bias ? g.bias[n] : 0.f;
@@ -172,8 +234,25 @@ extern "C" int sgic_gemm_f32(const float *d_A, int lda, const float *d_W, int ld
   SGIC_REQUIRE(act >= 0 && act <= ACT_LRELU, "activation");
   SGIC_REQUIRE(a_seg >= 0 && c_seg >= 0 && (a_seg == 0 || a_seg_stride >= a_seg) && (c_seg == 0 || c_seg_stride >= c_seg),
                "row segment maps");
-  GemmArgs g{d_A, d_W, d_bias, d_R, d_C, M, N, K, lda, ldw, ldr, ldc, act, (M + BM - 1) / BM, (N + BN - 1) / BN,
+  // Tile choice: 128x128 unless the 128x64 grid fills the last round of workgroups on the 256 CUs clearly
+  // better (workgroups are dispatched dynamically, so the makespan is ~ceil(blocks / 256) block-times).
+  const int tm = (M + BM - 1) / BM;
+  auto eff = [&](int bn) {
+    const double nb = (double)tm * ((N + bn - 1) / bn) / 256.0;
+    return nb / ceil(nb);
+  };
+  const bool narrow = N <= 64 || eff(64) > eff(128) + 0.04;
+  GemmArgs g{d_A, d_W, d_bias, d_R, d_C, M, N, K, lda, ldw, ldr, ldc, act, tm, narrow ? (N + 63) / 64 : (N + 127) / 128,
              a_seg, a_seg_stride, c_seg, c_seg_stride};
-  gemm_f32_kernel<<<g.tiles_m * g.tiles_n, 256, 0, to_stream(stream)>>>(g);
+  const bool ktail = (K % BK) != 0;
+  const unsigned grid = g.tiles_m * g.tiles_n;
+  hipStream_t st = to_stream(stream);
+  if (narrow) {
+    if (ktail) gemm_f32_kernel<1, true><<<grid, 256, 0, st>>>(g);
+    else gemm_f32_kernel<1, false><<<grid, 256, 0, st>>>(g);
+  } else {
+    if (ktail) gemm_f32_kernel<2, true><<<grid, 256, 0, st>>>(g);
+    else gemm_f32_kernel<2, false><<<grid, 256, 0, st>>>(g);
+  }
   return sgic::check_launch("gemm_f32_kernel");
 }
