@@ -54,6 +54,7 @@ struct GemmArgs {
   // optional row maps  row(m) = (m / seg) * seg_stride + (m % seg)  (seg == 0: identity) so a GEMM can
   // read / write the [:, a:b] token slice of an (n, L, C) buffer in place (models/cross_blocks.py:87-94)
   int a_seg, a_seg_stride, c_seg, c_seg_stride;
+  int vec_epilogue;  // C/R/bias rows are float4-addressable (N, ldc, ldr % 4 == 0, 16-byte aligned bases)
 };
 
 __device__ __forceinline__ f32x4 ld4_guard(const float *p, bool ok) {
@@ -74,8 +75,10 @@ template <int WN, bool KTAIL>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   constexpr int TBN = 64 * WN;          // workgroup tile N
   constexpr int NB4 = TBN / 32;         // float4 staged per thread for the W tile (TBN rows x 8 chunks / 256)
-  __shared__ __attribute__((aligned(16))) float sA[2][BM * LDS_LD];
-  __shared__ __attribute__((aligned(16))) float sB[2][TBN * LDS_LD];
+  // one LDS array: [A buf0 | A buf1 | W buf0 | W buf1]; the epilogue reuses it as 4 per-wave transpose tiles
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + TBN) * LDS_LD];
+  float(*sA)[BM * LDS_LD] = reinterpret_cast<float(*)[BM * LDS_LD]>(smem);
+  float(*sB)[TBN * LDS_LD] = reinterpret_cast<float(*)[TBN * LDS_LD]>(smem + 2 * BM * LDS_LD);
 
   // ---- XCD-aware bijective remap: hardware deals consecutive block ids round-robin over 8 XCDs ----
   const int nwg = g.tiles_m * g.tiles_n;
@@ -201,7 +204,44 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     mfma_frag(f1);
   }
 
-  // ---- epilogue: D[row = (e&3) + 8*(e>>2) + 4*lhalf][col = lrow] ----
+  // ---- epilogue.  Accumulator layout: D[row = (e&3) + 8*(e>>2) + 4*lhalf][col = lrow] ----
+  if (g.vec_epilogue) {
+    // Wide stores: each wave transposes its 64 x (32*WN) tile through its private slice of LDS (nobody reads
+    // the staging buffers after the last barrier) and writes whole 128/256-byte row segments as dwordx4 --
+    // 4x fewer store instructions than one dword per lane, which is what bounds a lock-stepped epilogue.
+    constexpr int TW = 32 * WN;            // wave tile width (floats)
+    constexpr int LPR = TW / 4;            // lanes per row (float4 each)
+    constexpr int RPI = 64 / LPR;          // rows per store instruction
+    float *ep = smem + wave * (64 * TW);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < WN; j++)
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+          ep[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf) * TW + j * 32 + lrow] = acc[i][j][e];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
+    const int n = n0 + wn + c4;
+    if (n < g.N) {  // N % 4 == 0 in this path, so a float4 is all-in or all-out
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (g.bias) bv = *reinterpret_cast<const f32x4 *>(g.bias + n);
+#pragma unroll
+      for (int it = 0; it < 64 / RPI; ++it) {
+        const int r = it * RPI + r0;
+        const int m = m0 + wm + r;
+        if (m < g.M) {
+          f32x4 v = *reinterpret_cast<const f32x4 *>(ep + r * TW + c4);
+#pragma unroll
+          for (int t = 0; t < 4; t++) v[t] = apply_act(v[t] + bv[t], g.act);
+          if (g.R) v += *reinterpret_cast<const f32x4 *>(g.R + (size_t)m * g.ldr + n);
+          const size_t crow = g.c_seg ? (size_t)(m / g.c_seg) * g.c_seg_stride + (m % g.c_seg) : (size_t)m;
+          *reinterpret_cast<f32x4 *>(g.C + crow * g.ldc + n) = v;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < WN; j++) {
     const int n = n0 + wn + j * 32 + lrow;
@@ -243,7 +283,9 @@ extern "C" int sgic_gemm_f32(const float *d_A, int lda, const float *d_W, int ld
   };
   const bool narrow = N <= 64 || eff(64) > eff(128) + 0.04;
   GemmArgs g{d_A, d_W, d_bias, d_R, d_C, M, N, K, lda, ldw, ldr, ldc, act, tm, narrow ? (N + 63) / 64 : (N + 127) / 128,
-             a_seg, a_seg_stride, c_seg, c_seg_stride};
+             a_seg, a_seg_stride, c_seg, c_seg_stride, 0};
+  g.vec_epilogue = (N % 4 == 0) && (ldc % 4 == 0) && (((uintptr_t)d_C) & 15) == 0 &&
+                   (!d_R || ((ldr % 4 == 0) && (((uintptr_t)d_R) & 15) == 0)) && (!d_bias || (((uintptr_t)d_bias) & 15) == 0);
   const bool ktail = (K % BK) != 0;
   const unsigned grid = g.tiles_m * g.tiles_n;
   hipStream_t st = to_stream(stream);
