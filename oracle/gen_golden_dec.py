@@ -1,0 +1,106 @@
+"""Decode-side golden vectors from the REAL reference modules (HybridDecoder, FeatMerge, taming Decoder,
+bottleneck.decompress) with synthetic weights, SMALL config; checks oracle/torch_ref.py on the spot.
+Build-container only.  Output: tests/golden/dec_small_<case>.npz.   Run after gen_golden_nn.py."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import ref_harness  # noqa: E402
+
+wrap = ref_harness.setup()
+import torch  # noqa: E402
+
+import sgic_amd  # noqa: E402,F401
+from sgic_amd import weights as W  # noqa: E402
+from sgic_amd.config import SMALL  # noqa: E402
+import torch_ref as TR  # noqa: E402
+
+from models.codec_sq_fixbpp import FeatMerge, Hybrid_Codec  # noqa: E402  (reference code)
+from taming.modules.diffusionmodules.model import Decoder as TamingDecoder  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+cfg = SMALL
+hc = Hybrid_Codec(wrap(cfg.titok_dict()), list(cfg.in_pos_enc), list(cfg.in_pos_dec), cfg.feat_dim, cfg.embed_dim, cfg.n_attn).eval()
+fm = FeatMerge(cfg.width, cfg.feat_dim, cfg.vq_n_embed).eval()
+td = TamingDecoder(**cfg.vqgan_ddconfig()).eval()
+pqc = torch.nn.Conv2d(cfg.vq_embed_dim, cfg.vq_z_channels, 1)
+
+spec = W.full_spec(cfg)
+sd = W.synth_weights(spec, seed=1234)
+
+
+def load(mod, prefix, extra_ok=()):
+    ref = mod.state_dict()
+    mine = {n[len(prefix):]: t for n, t in sd.items() if n.startswith(prefix)}
+    for k, v in ref.items():
+        assert k in mine, f"reference key not in inventory: {prefix}{k}"
+        assert tuple(v.shape) == tuple(mine[k].shape), (k, v.shape, mine[k].shape)
+    for k in mine:
+        assert k in ref or k.startswith(extra_ok), f"inventory key not in reference: {prefix}{k}"
+    mod.load_state_dict({k: v for k, v in mine.items() if k in ref}, strict=True)
+
+
+load(hc, "hybrid_codec.")
+load(fm, "prior_fusion.")
+load(td, "vqgan.decoder.")
+pqc.load_state_dict({"weight": sd["vqgan.post_quant_conv.weight"], "bias": sd["vqgan.post_quant_conv.bias"]})
+print("decode-side inventory ok:", len(spec), "tensors")
+emb = sd["vqgan.quantize.embedding.weight"]
+
+bn = hc.quantize_feat
+bn.force_zero_thres = cfg.force_zero_thres
+bn.update(force=True)
+
+for case in "abc":
+    g = np.load(os.path.join(OUT, f"nn_small_{case}.npz"))
+    B, H, Wimg = int(g["B"]), int(g["H"]), int(g["W"])
+    nH, nW = H // 256, Wimg // 256
+    hh, ww = H // 32, Wimg // 32
+    # ---- reference decode_only, image by image (codec_sq_fixbpp.py:881-901 without torchac) ----
+    x_hats, h_hats, z_hats, titoks, feats, logits_l, latents = [], [], [], [], [], [], []
+    T = cfg.num_latent_tokens
+    for b in range(B):
+        idx = torch.from_numpy(g["vq_idx"][b * nH * nW * T:(b + 1) * nH * nW * T]).int()
+        z_hat = hc.quantize.get_codebook_entry(idx)
+        z_hat = z_hat.reshape(nH * nW, T, -1).permute(0, 2, 1).unsqueeze(2).contiguous()   # "(l n) c -> l c n"
+        z_hat = torch.nn.functional.normalize(z_hat, dim=1)
+        h_hat = bn.decompress(g[f"stream_{b}"].tobytes(), torch.Size([1, cfg.feat_dim, hh, ww]), 0)
+        titok, feat = hc.decoder(z_hat, h_hat, (nH, nW))
+        logit = fm(titok, feat)
+        latent = torch.einsum("nchw,cd->ndhw", logit.softmax(1), emb)
+        x_hat = td(pqc(latent)).clamp(-1.0, 1.0)
+        for lst, v in ((x_hats, x_hat), (h_hats, h_hat), (z_hats, z_hat), (titoks, titok), (feats, feat), (logits_l, logit), (latents, latent)):
+            lst.append(v)
+    x_hat, h_hat, z_hat, titok, feat, logit, latent = (torch.cat(v) for v in (x_hats, h_hats, z_hats, titoks, feats, logits_l, latents))
+    print(f"case {case}: x_hat {tuple(x_hat.shape)} range [{x_hat.min():.3f},{x_hat.max():.3f}] |titok|max {titok.abs().max():.2f} "
+          f"|feat|max {feat.abs().max():.2f} |logit|max {logit.abs().max():.2f}")
+
+    # ---- restatement vs reference ----
+    def rel(a, b):
+        return float((a - b).abs().max() / max(1e-6, float(b.abs().max())))
+    sym = torch.from_numpy(g["sym"]).clone()
+    sym[torch.from_numpy(g["idx"]) < 0] = 0
+    yh = torch.cat([TR.four_part_prior_decode(sym[b:b + 1], sd, cfg.force_zero_thres, 1, hh, ww)[0] for b in range(B)])
+    h2 = torch.cat([TR.bottleneck_synthesis(yh[b:b + 1], sd) for b in range(B)])
+    z2 = TR.z_from_indices(torch.from_numpy(g["vq_idx"]), B * nH * nW, sd, cfg)
+    t2, f2 = TR.decoder_forward(z_hat, h_hat, (nH, nW), sd, cfg)
+    l2 = TR.featmerge_forward(titok, feat, sd, cfg)
+    lat2 = TR.soft_lookup(logit, sd)
+    x2 = TR.vqgan_decode(latent, sd, cfg).clamp(-1, 1)
+    errs = dict(h_hat=rel(h2, h_hat), z_hat=rel(z2, z_hat), titok=rel(t2, titok), feat=rel(f2, feat), logits=rel(l2, logit),
+                latent=rel(lat2, latent), x_hat=rel(x2, x_hat))
+    print("   torch_ref vs reference rel err:", {k: f"{v:.1e}" for k, v in errs.items()})
+    assert all(v < 2e-4 for v in errs.values()), errs
+    if case == "a":   # full intermediates for the single-tile case
+        np.savez_compressed(os.path.join(OUT, f"dec_small_{case}.npz"), h_hat=h_hat.numpy(), z_hat=z_hat.numpy(),
+                            titok=titok.numpy(), feat=feat.numpy(), logits=logit.numpy(), latent=latent.numpy(), x_hat=x_hat.numpy())
+    else:             # multi-tile cases: small tensors in full, the big ones as a stride-4 / stride-2 spatial sample
+        np.savez_compressed(os.path.join(OUT, f"dec_small_{case}.npz"), h_hat=h_hat.numpy(), z_hat=z_hat.numpy(),
+                            titok_s2=titok[:, :, ::2, ::2].numpy(), feat_s2=feat[:, :, ::2, ::2].numpy(),
+                            latent_s2=latent[:, :, ::2, ::2].numpy(), x_hat_s4=x_hat[:, :, ::4, ::4].numpy())
+print("done")

@@ -272,3 +272,148 @@ def clip_tower(x, sd, cfg, p="clip.visual"):
     pooled = F.layer_norm(x[:, 0], (Wd,), sd[f"{p}.ln_post.weight"], sd[f"{p}.ln_post.bias"])
     z = pooled @ sd[f"{p}.proj"]
     return z / z.norm(dim=-1, keepdim=True)
+
+
+# ---------------------------------------------------------------------------------------------
+# decode side (D1-D5)
+# ---------------------------------------------------------------------------------------------
+def four_part_prior_decode(sym, sd, thr, B, H, W, p="hybrid_codec.quantize_feat"):
+    """decompress_four_part_prior (entropy/compression_model.py:377-418) given the already entropy-decoded
+    symbols sym (B,4,16,H,W) (0 where skipped).  Also returns the per-step indexes it would request."""
+    C = sd[f"{p}.factorized_prior_vec"].shape[1]
+    params = prior_params(B, H, W, sd, p)
+    qs, scales, means = params.chunk(3, 1)
+    common = F.conv2d(params, sd[f"{p}.y_spatial_prior_reduction.weight"], sd[f"{p}.y_spatial_prior_reduction.bias"])
+    masks = four_part_masks(B, C, H, W)
+    qs = torch.clamp_min(qs, 0.5)
+    log_min, log_step = math.log(0.11), (math.log(64.0) - math.log(0.11)) / 255
+    y_hat_so_far, idxs = None, []
+    for k in range(4):
+        if k > 0:
+            t = dcb4(torch.cat((y_hat_so_far, common), 1), sd, f"{p}.y_spatial_prior_adaptor_{k}")
+            for j in range(3):
+                t = dcb4(t, sd, f"{p}.y_spatial_prior.{j}")
+            scales, means = t.chunk(2, 1)
+        m = masks[k]
+        x0, x1, x2, x3 = (scales * m).chunk(4, 1)
+        sc_r = (x0 + x1) + (x2 + x3)
+        sc = torch.maximum(sc_r, torch.zeros_like(sc_r) + 1e-5)
+        ind = ((torch.log(sc) - log_min) / log_step).clamp_(0, 255)
+        idxs.append(torch.where(sc_r < thr, torch.zeros_like(ind) - 1, ind).to(torch.int16))
+        yq = sym[:, k].float()
+        cur = (torch.cat((yq, yq, yq, yq), 1) + means) * m
+        y_hat_so_far = cur if y_hat_so_far is None else y_hat_so_far + cur
+    return y_hat_so_far * qs, torch.stack(idxs, 1)
+
+
+def bottleneck_synthesis(y_hat, sd, p="hybrid_codec.quantize_feat"):
+    """decode (models/sq_bottleneck.py:115-119)"""
+    h = dcb4(dcb4(y_hat, sd, f"{p}.dec_trans_0.0"), sd, f"{p}.dec_trans_0.1")
+    h = h * sd[f"{p}.dec_q"][0:1]
+    return dcb4(dcb4(h, sd, f"{p}.dec_trans_1.0"), sd, f"{p}.dec_trans_1.1")
+
+
+def z_from_indices(idx, n_tiles, sd, cfg, p="hybrid_codec.quantize"):
+    """decode_only's z branch (codec_sq_fixbpp.py:889-892): codebook rows -> (N,12,1,32), l2-normalised over c"""
+    e = sd[f"{p}.embedding.weight"][idx.long()]                      # (N*T, c)
+    z = e.reshape(n_tiles, cfg.num_latent_tokens, -1).permute(0, 2, 1).unsqueeze(2).contiguous()
+    return F.normalize(z, dim=1)
+
+
+def decoder_forward(z_hat, h_hat, stack_shape, sd, cfg, p="hybrid_codec.decoder"):
+    """HybridDecoder.forward (models/codec_sq_fixbpp.py:248-300)"""
+    nH, nW = stack_shape
+    Wd, Fd, P, T = cfg.width, cfg.feat_dim, cfg.grid, cfg.num_latent_tokens
+    N = z_hat.shape[0]
+    x = z_hat.reshape(N, -1, T).permute(0, 2, 1)
+    x = F.linear(x, sd[f"{p}.decoder_embed.weight"], sd[f"{p}.decoder_embed.bias"])
+    mt = sd[f"{p}.mask_token"].repeat(N, P * P, 1)
+    mt = torch.cat([sd[f"{p}.class_embedding"].unsqueeze(0).expand(N, -1, -1), mt], dim=1) + sd[f"{p}.positional_embedding"]
+    x = torch.cat([mt, x + sd[f"{p}.latent_token_positional_embedding"][:T]], dim=1)
+    feat = F.conv2d(h_hat, sd[f"{p}.init_feat_up.0.weight"], sd[f"{p}.init_feat_up.0.bias"])
+    feat = F.pixel_shuffle(feat, 2)
+    feat = swin_stack(feat, sd, f"{p}.init_feat_up.2", 4, cfg.window)
+    x = F.layer_norm(x, (Wd,), sd[f"{p}.ln_pre.weight"], sd[f"{p}.ln_pre.bias"]).permute(1, 0, 2)
+    for i in range(cfg.layers):
+        x = rab(x, sd, f"{p}.transformer.{i}", cfg.heads)
+        if i in cfg.in_pos_dec:
+            feat, x = cross_block(feat, x, (nH, nW), sd, f"{p}.inter_blocks.{i}", cfg)
+            feat = swin_stack(feat, sd, f"{p}.feat_blocks.{i}.0", 2, cfg.window)
+            feat = convnext(feat, sd, f"{p}.feat_blocks.{i}.1")
+            feat = convnext(feat, sd, f"{p}.feat_blocks.{i}.2")
+    x = x.permute(1, 0, 2)[:, 1:1 + P * P]
+    x = F.layer_norm(x, (Wd,), sd[f"{p}.ln_post.weight"], sd[f"{p}.ln_post.bias"])
+    x = x.permute(0, 2, 1).reshape(N, Wd, P, P)
+    B = N // (nH * nW)
+    x = x.reshape(B, nH, nW, Wd, P, P).permute(0, 3, 1, 4, 2, 5).reshape(B, Wd, nH * P, nW * P)
+    return x, feat
+
+
+def featmerge_forward(titok, feat, sd, cfg, p="prior_fusion"):
+    """FeatMerge.forward -> logits (B, n_embed, H, W) (models/codec_sq_fixbpp.py:427-439)"""
+    t = swin_stack(titok.permute(0, 2, 3, 1).contiguous(), sd, f"{p}.titok_in.1", 2, cfg.window, first_index=0, bchw=False)
+    f = swin_stack(feat.permute(0, 2, 3, 1).contiguous(), sd, f"{p}.feat_in.1", 2, cfg.window, first_index=0, bchw=False)
+    h = F.linear(torch.cat([t, f], dim=-1), sd[f"{p}.merge.0.weight"], sd[f"{p}.merge.0.bias"])
+    h = F.silu(F.layer_norm(h, (h.shape[-1],), sd[f"{p}.merge.1.weight"], sd[f"{p}.merge.1.bias"]))
+    h = F.linear(h, sd[f"{p}.merge.3.weight"], sd[f"{p}.merge.3.bias"])
+    h = swin_stack(h, sd, f"{p}.merge.4", 4, cfg.window, first_index=0, bchw=False)
+    h = F.layer_norm(h, (h.shape[-1],), sd[f"{p}.ffn.0.weight"], sd[f"{p}.ffn.0.bias"])
+    h = F.linear(torch.tanh(F.linear(h, sd[f"{p}.ffn.1.weight"], sd[f"{p}.ffn.1.bias"])), sd[f"{p}.ffn.3.weight"], sd[f"{p}.ffn.3.bias"])
+    return h.permute(0, 3, 1, 2).contiguous()
+
+
+def soft_lookup(logits, sd, p="vqgan"):
+    """decode_to_latent's soft codebook lookup (codec_sq_fixbpp.py:660-662)"""
+    return torch.einsum("nchw,cd->ndhw", logits.softmax(1), sd[f"{p}.quantize.embedding.weight"])
+
+
+def _gn(x, sd, p):
+    return F.group_norm(x, 32, sd[f"{p}.weight"], sd[f"{p}.bias"], eps=1e-6)
+
+
+def _swish(x):
+    return x * torch.sigmoid(x)
+
+
+def vq_resblock(x, sd, p):
+    """taming ResnetBlock, temb = None, dropout 0 (model.py:117-137)"""
+    h = F.conv2d(_swish(_gn(x, sd, f"{p}.norm1")), sd[f"{p}.conv1.weight"], sd[f"{p}.conv1.bias"], padding=1)
+    h = F.conv2d(_swish(_gn(h, sd, f"{p}.norm2")), sd[f"{p}.conv2.weight"], sd[f"{p}.conv2.bias"], padding=1)
+    if f"{p}.nin_shortcut.weight" in sd:
+        x = F.conv2d(x, sd[f"{p}.nin_shortcut.weight"], sd[f"{p}.nin_shortcut.bias"])
+    return x + h
+
+
+def vq_attnblock(x, sd, p):
+    """taming AttnBlock (model.py:168-192)"""
+    h = _gn(x, sd, f"{p}.norm")
+    q = F.conv2d(h, sd[f"{p}.q.weight"], sd[f"{p}.q.bias"])
+    k = F.conv2d(h, sd[f"{p}.k.weight"], sd[f"{p}.k.bias"])
+    v = F.conv2d(h, sd[f"{p}.v.weight"], sd[f"{p}.v.bias"])
+    b, c, hh, ww = q.shape
+    w_ = torch.bmm(q.reshape(b, c, -1).permute(0, 2, 1), k.reshape(b, c, -1)) * (int(c) ** (-0.5))
+    w_ = F.softmax(w_, dim=2).permute(0, 2, 1)
+    h = torch.bmm(v.reshape(b, c, -1), w_).reshape(b, c, hh, ww)
+    return x + F.conv2d(h, sd[f"{p}.proj_out.weight"], sd[f"{p}.proj_out.bias"])
+
+
+def vqgan_decode(latent, sd, cfg, p="vqgan"):
+    """decode_to_image: post_quant_conv + taming Decoder.forward (codec_sq_fixbpp.py:666-669, model.py:506-537)"""
+    import sgic_amd.weights as W  # plan helper only (pure python)
+    plan, _, _ = W.vqgan_plan(cfg)
+    d = f"{p}.decoder"
+    h = F.conv2d(latent, sd[f"{p}.post_quant_conv.weight"], sd[f"{p}.post_quant_conv.bias"])
+    h = F.conv2d(h, sd[f"{d}.conv_in.weight"], sd[f"{d}.conv_in.bias"], padding=1)
+    h = vq_resblock(h, sd, f"{d}.mid.block_1")
+    h = vq_attnblock(h, sd, f"{d}.mid.attn_1")
+    h = vq_resblock(h, sd, f"{d}.mid.block_2")
+    for lvl, blocks, up in plan:
+        for i, (cin, cout, attn) in enumerate(blocks):
+            h = vq_resblock(h, sd, f"{d}.up.{lvl}.block.{i}")
+            if attn:
+                h = vq_attnblock(h, sd, f"{d}.up.{lvl}.attn.{i}")
+        if up:
+            h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+            h = F.conv2d(h, sd[f"{d}.up.{lvl}.upsample.conv.weight"], sd[f"{d}.up.{lvl}.upsample.conv.bias"], padding=1)
+    h = _swish(_gn(h, sd, f"{d}.norm_out"))
+    return F.conv2d(h, sd[f"{d}.conv_out.weight"], sd[f"{d}.conv_out.bias"], padding=1)

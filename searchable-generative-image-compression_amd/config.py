@@ -20,6 +20,15 @@ class CodecConfig:
     codebook_size: int = 4096
     window: int = 16
     force_zero_thres: float = 0.12                 # compress.py:238
+    # generative decoder: FeatMerge + taming VQGAN (config_test.yaml:37-54, codec_sq_fixbpp.py:395-439)
+    fm_inner: int = 1024
+    vq_ch: int = 128
+    vq_ch_mult: Tuple[int, ...] = (1, 1, 2, 2, 4)
+    vq_num_res_blocks: int = 2
+    vq_attn_resolutions: Tuple[int, ...] = (16,)
+    vq_embed_dim: int = 256
+    vq_n_embed: int = 256
+    vq_z_channels: int = 256
 
     @property
     def width(self):
@@ -46,11 +55,18 @@ class CodecConfig:
                                        "num_latent_tokens": self.num_latent_tokens}},
                 "dataset": {"preprocessing": {"crop_size": self.crop_size}}}
 
+    def vqgan_ddconfig(self):
+        """`vqganconfig.ddconfig` of the reference (config_test.yaml:44-54)"""
+        return dict(double_z=False, z_channels=self.vq_z_channels, resolution=self.crop_size, in_channels=3, out_ch=3,
+                    ch=self.vq_ch, ch_mult=list(self.vq_ch_mult), num_res_blocks=self.vq_num_res_blocks,
+                    attn_resolutions=list(self.vq_attn_resolutions), dropout=0.0)
+
 
 LARGE = CodecConfig()
 # small configuration used by fast parity tests / golden fixtures (same topology, 8 layers, width 512,
 # detail width 256, cross stages after layers 1 and 5)
-SMALL = CodecConfig(model_size="small", feat_dim=256, in_pos_enc=(1, 5), in_pos_dec=(1, 5))
+SMALL = CodecConfig(model_size="small", feat_dim=256, in_pos_enc=(1, 5), in_pos_dec=(1, 5),
+                    vq_ch=32, vq_embed_dim=64, vq_n_embed=64, vq_z_channels=64)
 
 
 @dataclass(frozen=True)

@@ -97,6 +97,104 @@ def encoder_spec(cfg: CodecConfig, prefix="hybrid_codec.encoder"):
     return o
 
 
+def decoder_spec(cfg: CodecConfig, prefix="hybrid_codec.decoder"):
+    """HybridDecoder (codec_sq_fixbpp.py:186-246 + titok/blocks.py:147-190; TiTok's ffn is removed, :195)"""
+    W, F, P, T, g = cfg.width, cfg.feat_dim, cfg.patch_size, cfg.num_latent_tokens, cfg.grid
+    o = [(f"{prefix}.decoder_embed.weight", (W, cfg.token_size), "lin"), (f"{prefix}.decoder_embed.bias", (W,), "bias"),
+         (f"{prefix}.class_embedding", (1, W), "emb"), (f"{prefix}.positional_embedding", (g * g + 1, W), "emb"),
+         (f"{prefix}.mask_token", (1, 1, W), "emb"), (f"{prefix}.latent_token_positional_embedding", (T, W), "emb"),
+         (f"{prefix}.ln_pre.weight", (W,), "ln_w"), (f"{prefix}.ln_pre.bias", (W,), "ln_b")]
+    for i in range(cfg.layers):
+        _rab(f"{prefix}.transformer.{i}", W, o)
+    o += [(f"{prefix}.ln_post.weight", (W,), "ln_w"), (f"{prefix}.ln_post.bias", (W,), "ln_b"),
+          (f"{prefix}.init_feat_up.0.weight", (4 * F, F, 1, 1), "lin"), (f"{prefix}.init_feat_up.0.bias", (4 * F,), "bias")]
+    _swin_stack(f"{prefix}.init_feat_up.2", F, 4, cfg.window, o)
+    for i in cfg.in_pos_dec:
+        _cross(f"{prefix}.inter_blocks.{i}", W, F, cfg.n_attn, g, T, o)
+        _swin_stack(f"{prefix}.feat_blocks.{i}.0", F, 2, cfg.window, o)
+        _convnext(f"{prefix}.feat_blocks.{i}.1", F, o)
+        _convnext(f"{prefix}.feat_blocks.{i}.2", F, o)
+    return o
+
+
+def featmerge_spec(cfg: CodecConfig, prefix="prior_fusion"):
+    """FeatMerge (codec_sq_fixbpp.py:395-425)"""
+    W, F, I = cfg.width, cfg.feat_dim, cfg.fm_inner
+    o = []
+    _swin_stack(f"{prefix}.feat_in.1", F, 2, cfg.window, o, first_index=0)
+    _swin_stack(f"{prefix}.titok_in.1", W, 2, cfg.window, o, first_index=0)
+    o += [(f"{prefix}.merge.0.weight", (2 * W, W + F), "lin"), (f"{prefix}.merge.0.bias", (2 * W,), "bias"),
+          (f"{prefix}.merge.1.weight", (2 * W,), "ln_w"), (f"{prefix}.merge.1.bias", (2 * W,), "ln_b"),
+          (f"{prefix}.merge.3.weight", (I, 2 * W), "lin"), (f"{prefix}.merge.3.bias", (I,), "bias")]
+    _swin_stack(f"{prefix}.merge.4", I, 4, cfg.window, o, first_index=0)
+    o += [(f"{prefix}.ffn.0.weight", (I,), "ln_w"), (f"{prefix}.ffn.0.bias", (I,), "ln_b"),
+          (f"{prefix}.ffn.1.weight", (2 * I, I), "lin"), (f"{prefix}.ffn.1.bias", (2 * I,), "bias"),
+          (f"{prefix}.ffn.3.weight", (cfg.vq_n_embed, 2 * I), "lin"), (f"{prefix}.ffn.3.bias", (cfg.vq_n_embed,), "bias")]
+    return o
+
+
+def _vq_res(prefix, cin, cout, o):
+    o += [(f"{prefix}.norm1.weight", (cin,), "ln_w"), (f"{prefix}.norm1.bias", (cin,), "ln_b"),
+          (f"{prefix}.conv1.weight", (cout, cin, 3, 3), "lin"), (f"{prefix}.conv1.bias", (cout,), "bias"),
+          (f"{prefix}.norm2.weight", (cout,), "ln_w"), (f"{prefix}.norm2.bias", (cout,), "ln_b"),
+          (f"{prefix}.conv2.weight", (cout, cout, 3, 3), "lin"), (f"{prefix}.conv2.bias", (cout,), "bias")]
+    if cin != cout:
+        o += [(f"{prefix}.nin_shortcut.weight", (cout, cin, 1, 1), "lin"), (f"{prefix}.nin_shortcut.bias", (cout,), "bias")]
+
+
+def _vq_attn(prefix, c, o):
+    o += [(f"{prefix}.norm.weight", (c,), "ln_w"), (f"{prefix}.norm.bias", (c,), "ln_b")]
+    for n in ("q", "k", "v", "proj_out"):
+        o += [(f"{prefix}.{n}.weight", (c, c, 1, 1), "lin"), (f"{prefix}.{n}.bias", (c,), "bias")]
+
+
+def vqgan_plan(cfg: CodecConfig):
+    """level-by-level plan of the taming Decoder (model.py:436-537): list of (i_level, [(cin, cout, attn)], upsample)"""
+    nres = len(cfg.vq_ch_mult)
+    block_in = cfg.vq_ch * cfg.vq_ch_mult[-1]
+    res = cfg.crop_size // 2 ** (nres - 1)
+    plan = []
+    for lvl in reversed(range(nres)):
+        out = cfg.vq_ch * cfg.vq_ch_mult[lvl]
+        blocks = []
+        for _ in range(cfg.vq_num_res_blocks + 1):
+            blocks.append((block_in, out, res in cfg.vq_attn_resolutions))
+            block_in = out
+        plan.append((lvl, blocks, lvl != 0))
+        if lvl != 0:
+            res *= 2
+    return plan, cfg.vq_ch * cfg.vq_ch_mult[-1], block_in
+
+
+def vqgan_spec(cfg: CodecConfig, prefix="vqgan"):
+    """the parts of the taming VQGAN the decoder path uses: codebook, post_quant_conv, Decoder"""
+    plan, c0, c_last = vqgan_plan(cfg)
+    o = [(f"{prefix}.quantize.embedding.weight", (cfg.vq_n_embed, cfg.vq_embed_dim), "codebook"),
+         (f"{prefix}.post_quant_conv.weight", (cfg.vq_z_channels, cfg.vq_embed_dim, 1, 1), "lin"),
+         (f"{prefix}.post_quant_conv.bias", (cfg.vq_z_channels,), "bias"),
+         (f"{prefix}.decoder.conv_in.weight", (c0, cfg.vq_z_channels, 3, 3), "lin"), (f"{prefix}.decoder.conv_in.bias", (c0,), "bias")]
+    _vq_res(f"{prefix}.decoder.mid.block_1", c0, c0, o)
+    _vq_attn(f"{prefix}.decoder.mid.attn_1", c0, o)
+    _vq_res(f"{prefix}.decoder.mid.block_2", c0, c0, o)
+    for lvl, blocks, up in plan:
+        for i, (cin, cout, attn) in enumerate(blocks):
+            _vq_res(f"{prefix}.decoder.up.{lvl}.block.{i}", cin, cout, o)
+            if attn:
+                _vq_attn(f"{prefix}.decoder.up.{lvl}.attn.{i}", cout, o)
+        if up:
+            c = blocks[-1][1]
+            o += [(f"{prefix}.decoder.up.{lvl}.upsample.conv.weight", (c, c, 3, 3), "lin"),
+                  (f"{prefix}.decoder.up.{lvl}.upsample.conv.bias", (c,), "bias")]
+    o += [(f"{prefix}.decoder.norm_out.weight", (c_last,), "ln_w"), (f"{prefix}.decoder.norm_out.bias", (c_last,), "ln_b"),
+          (f"{prefix}.decoder.conv_out.weight", (3, c_last, 3, 3), "lin"), (f"{prefix}.decoder.conv_out.bias", (3,), "bias")]
+    return o
+
+
+def full_spec(cfg: CodecConfig):
+    return (encoder_spec(cfg) + codec_misc_spec(cfg) + bottleneck_spec(cfg) + decoder_spec(cfg) + featmerge_spec(cfg) +
+            vqgan_spec(cfg))
+
+
 def codec_misc_spec(cfg: CodecConfig, prefix="hybrid_codec"):
     """latent tokens + TiTok codebook (codec_sq_fixbpp.py:311-323)"""
     return [(f"{prefix}.latent_tokens", (cfg.num_latent_tokens, cfg.width), "emb"),
