@@ -146,7 +146,7 @@ int sgic_dwconv_nhwc(const float *d_x, const float *d_w, const float *d_bias, co
 int sgic_im2col_2x2(const float *d_x, int B, int H, int W, int C, int tile16, float *d_out, sgic_stream_t stream);
 /* ConvFFN3 gate (blocks/dcvc.py:50-53). */
 int sgic_gated_lrelu(const float *d_x, float *d_out, int M, int C2, sgic_stream_t stream);
-/* y = x * v (mode 0) or x / max(v, 0.5) (mode 1), v row m % vrows (sq_bottleneck.py:111,117;
+/* y = x * v (mode 0), x / max(v, 0.5) (mode 1) or x * max(v, 0.5) (mode 2), v row m % vrows (sq_bottleneck.py:111,117;
  * compression_model.py:325-326,355). */
 int sgic_colop(const float *d_x, int ldx, const float *d_v, int ldv, int vrows, float *d_y, int ldy, int M, int C,
                int mode, sgic_stream_t stream);
@@ -165,6 +165,37 @@ int sgic_clip_preprocess(const float *d_x, long img_stride, long ch_stride, int 
                          sgic_stream_t stream);
 /* unit-normalise rows + u8 quantise (compress.py:73,77). */
 int sgic_l2norm_u8(const float *d_x, int ldx, int M, int D, float *d_unit, uint8_t *d_q, sgic_stream_t stream);
+
+/* Batched GEMM (element strides, 0 = shared operand) -- VQGAN AttnBlock single-head attention as
+ * S_b = Q_b K_b^T, O_b = P_b V_b (taming/modules/diffusionmodules/model.py:168-192). */
+int sgic_gemm_batched_f32(const float *d_A, int lda, long strideA, const float *d_W, int ldw, long strideW,
+                          const float *d_bias, const float *d_R, int ldr, long strideR, float *d_C, int ldc,
+                          long strideC, int M, int N, int K, int act, int batch, sgic_stream_t stream);
+/* 3x3/s1/p1 Conv2d as an implicit GEMM on the matrix cores over a zero-halo NHWC input [B,H+2,W+2,Cin]
+ * (Cin % 32 == 0); weights [Cout][(ky,kx,cin)]; fused bias/activation/residual (model.py:38-137,436-537). */
+int sgic_conv3x3_f32(const float *d_in_halo, const float *d_W, const float *d_bias, const float *d_R, int ldr,
+                     float *d_out, int ldc, int B, int H, int W, int Cin, int Cout, int act, sgic_stream_t stream);
+/* GroupNorm(groups, eps) on NHWC + optional swish; output plain or into the interior of a zero-halo buffer.
+ * d_ws: B*64*C*2 doubles, d_stats: B*groups*2 floats (model.py:34-35,117-131). */
+int sgic_groupnorm_nhwc(const float *d_x, const float *d_gamma, const float *d_beta, int B, int H, int W, int C,
+                        int groups, float eps, int swish, int halo_out, double *d_ws, float *d_stats, float *d_y,
+                        sgic_stream_t stream);
+/* copy (optionally nearest-2x upsampled, optionally from tile-major rows) into the interior of a zero-halo
+ * buffer [B, OH+2, OW+2, C] (Upsample, model.py:49-53). */
+int sgic_halo_copy(const float *d_in, int B, int H, int W, int C, int upsample2x, int tile16, float *d_out,
+                   sgic_stream_t stream);
+/* y = softmax(scale * x) over rows of length L (model.py:181-183; codec_sq_fixbpp.py:660-661). */
+int sgic_softmax_rows(const float *d_x, float *d_y, long M, int L, float scale, sgic_stream_t stream);
+/* PixelShuffle(2) of a plain [(b,y,x), 4C] map into tile-major [(b,2y+i,2x+j), C] (codec_sq_fixbpp.py:203-207). */
+int sgic_pixel_shuffle2_tm16(const float *d_in, int B, int H, int W, int C, float *d_out, sgic_stream_t stream);
+/* decoder tokens [cls+pos0 ; mask+pos ; emb+latpos] (codec_sq_fixbpp.py:258-267). */
+int sgic_assemble_dec_tokens(const float *d_emb, const float *d_cls, const float *d_mask, const float *d_pos,
+                             const float *d_latpos, int N, int P, int T, int D, float *d_out, sgic_stream_t stream);
+/* z_hat rows: codebook[idx] l2-normalised, zero-padded to ld floats (codec_sq_fixbpp.py:889-892). */
+int sgic_codebook_gather_norm(const int32_t *d_idx, const float *d_codebook, int M, int dim, int ld, float *d_out,
+                              sgic_stream_t stream);
+/* x_hat [(b,y,x), ld>=3] -> clamp(-1,1) -> NCHW (codec_sq_fixbpp.py:901). */
+int sgic_nhwc3_to_nchw_clamp(const float *d_in, int ld, int B, int H, int W, float *d_out, sgic_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -94,6 +94,8 @@ class BottleneckHIP:
         self.fusion = [D("y_prior_fusion.0"), D("y_prior_fusion.1")]
         self.red_w = _dev(sd[f"{p}.y_spatial_prior_reduction.weight"].reshape(Q, 3 * Q), device)
         self.red_b = _dev(sd[f"{p}.y_spatial_prior_reduction.bias"], device)
+        self.dec0 = [D("dec_trans_0.0"), D("dec_trans_0.1")] if f"{p}.dec_trans_0.0.block.0.conv1.0.weight" in sd else None
+        self.dec1 = [D("dec_trans_1.0"), D("dec_trans_1.1")] if self.dec0 else None
         self.adaptor = [None] + [D(f"y_spatial_prior_adaptor_{k}") for k in (1, 2, 3)]
         self.prior = [D(f"y_spatial_prior.{k}") for k in range(3)]
         self._prior_cache = {}
@@ -158,6 +160,57 @@ class BottleneckHIP:
         n = 4 * (self.Q // 4) * H * W
         out, meta = ops.rans_encode_batch(self.tables.handles[self.group], sym, idx, B, n)
         return out, meta, sym, idx
+
+    def synthesis(self, y_hat, B, H, W):
+        """decode (models/sq_bottleneck.py:115-119)"""
+        h = dcb4_forward(dcb4_forward(y_hat, self.dec0[0], B, H, W), self.dec0[1], B, H, W)
+        h = ops.colop(h, self.dec_q, 0)
+        return dcb4_forward(dcb4_forward(h, self.dec1[0], B, H, W), self.dec1[1], B, H, W)
+
+    def decode_latent(self, streams, off, ln, cap, B, H, W):
+        """decompress_four_part_prior for a batch (entropy/compression_model.py:377-418): the 4 x {prior NN ->
+        indexes -> rANS decode -> dequantise} dependency chain runs entirely on the GPU, all B streams in
+        parallel (one lane per stream, cursor kept in HBM between steps).  streams (B,cap) u8 on device."""
+        Q, hw = self.Q, H * W
+        paramsB, commonB = self._prior(B, H, W)
+        ctx = torch.zeros(B * hw, 2 * Q, device=self.device)
+        ops.add_rows_bcast(commonB, hw, None, ctx[:, Q:], hw, B, hw)
+        n = (Q // 4) * hw
+        sym = torch.zeros(B, 4, Q // 4, H, W, dtype=torch.int16, device=self.device)
+        idx = torch.zeros_like(sym)
+        thr = self.force_zero_thres
+        tab = self.tables.handles[self.group]
+        state = ops.rans_decode_init(streams, cap, off, ln, B)
+        sym_f, idx_f = sym.view(-1), idx.view(-1)
+        for k in range(4):
+            if k == 0:
+                sc, mu, ld = paramsB[:, Q:2 * Q], paramsB[:, 2 * Q:], 3 * Q
+            else:
+                t = dcb4_forward(ctx, self.adaptor[k], B, H, W)
+                for w in self.prior:
+                    t = dcb4_forward(t, w, B, H, W)
+                sc, mu, ld = t[:, 0:Q], t[:, Q:], 2 * Q
+            ops.index_step(sc, ld, B, H, W, Q, k, thr, idx)
+            ops.rans_decode_step(tab, streams, cap, off, ln, B, state, idx_f[k * n:], n, 4 * n, sym_f[k * n:], 4 * n)
+            ops.dequant_step(sym, mu, ld, ctx, 2 * Q, B, H, W, Q, k)
+        y_hat = ops.colop(ctx[:, 0:Q], paramsB[:, 0:Q], 2)           # y_hat_so_far * clamp_min(q_step, 0.5)
+        return y_hat, state, sym, idx
+
+    def decompress(self, h_streams, B, H, W):
+        """Compressive_bottleneck_varbpp_type2.decompress for a batch (models/sq_bottleneck.py:185-199):
+        list of B h_bit_stream byte strings -> h_hat [(B*H*W), Fd] plain NHWC on device"""
+        if self.tables is None:
+            raise RuntimeError("call update(force=True) first")
+        cap = max(len(s) for s in h_streams)
+        buf = np.zeros((B, cap), dtype=np.uint8)
+        for b, s in enumerate(h_streams):
+            buf[b, :len(s)] = np.frombuffer(s, dtype=np.uint8)
+        streams = torch.from_numpy(buf).to(self.device)
+        ln = torch.tensor([len(s) for s in h_streams], dtype=torch.int32, device=self.device)
+        y_hat, state, _, _ = self.decode_latent(streams, None, ln, cap, B, H, W)
+        if int(state[:, 2].abs().sum().item()) != 0:
+            raise RuntimeError("corrupt h_bit_stream: rANS decoder ran past the end of a stream or hit a bad index")
+        return self.synthesis(y_hat, B, H, W)
 
     @staticmethod
     def streams_to_host(out, meta):

@@ -48,6 +48,8 @@ class Codec:
         self.bottleneck = BottleneckHIP(state_dict, cfg, self.device)
         self.codebook = state_dict["hybrid_codec.quantize.embedding.weight"].to(self.device).float().contiguous()
         self.hybrid_codec = _HybridCodecProxy(self.bottleneck)
+        self._sd = state_dict
+        self._dec = None
 
     def to(self, device):
         return self
@@ -89,6 +91,51 @@ class Codec:
                 "z_indices_shape": torch.Size([nH * nW, cfg.token_size, 1, cfg.num_latent_tokens]),
             })
         return res
+
+    # ------------------------------------------------------------------ decode side
+    def _decoder(self):
+        """decode-side weights are loaded on first use (a compress-only process never pays for them)"""
+        if self._dec is None:
+            from .decoder import FeatMergeHIP, HybridDecoderHIP, VqganDecoderHIP
+            if "hybrid_codec.decoder.ln_pre.weight" not in self._sd:
+                raise RuntimeError("state_dict has no decoder weights (hybrid_codec.decoder.*, prior_fusion.*, vqgan.*)")
+            self._dec = (HybridDecoderHIP(self._sd, self.cfg, self.device), FeatMergeHIP(self._sd, self.cfg, self.device),
+                         VqganDecoderHIP(self._sd, self.cfg, self.device))
+        return self._dec
+
+    def decode_batch(self, enc_results, taps=None):
+        """B enc_result dicts with identical shapes (what encode_batch returned / unpack_c2df read) ->
+        x_hat (B,3,H,W) on device, clamped to [-1,1]  (codec_sq_fixbpp.py:881-901)"""
+        cfg = self.cfg
+        B = len(enc_results)
+        e0 = enc_results[0]
+        H, W = (int(v) for v in e0["img_shape"])
+        nH, nW = (int(v) for v in e0["stack_shape"])
+        ntok = int(e0["token_length"])
+        hh, ww = int(e0["feat_shape"][2]), int(e0["feat_shape"][3])
+        hyb, fm, vq = self._decoder()
+        # z branch: 12-bit unpack -> codebook rows -> l2 norm
+        zb = np.stack([np.frombuffer(e["z_bit_stream"], dtype=np.uint8) for e in enc_results])
+        zidx = ops.unpack12_batch(torch.from_numpy(zb).to(self.device), B, ntok)
+        z_rows = ops.codebook_gather_norm(zidx.view(-1), self.codebook)
+        # h branch
+        h_hat = self.bottleneck.decompress([bytes(e["h_bit_stream"]) for e in enc_results], B, hh, ww)
+        titok, feat = hyb.forward(z_rows, h_hat, B, (nH, nW))
+        if taps is not None:
+            taps.update(z_rows=z_rows.clone(), h_hat=h_hat.clone(), titok=titok.clone(), feat=feat.clone())
+        Hf, Wf = nH * cfg.grid, nW * cfg.grid
+        logits, latent = fm.forward(titok, feat, B, Hf, Wf)
+        if taps is not None:
+            taps.update(logits=logits.clone(), latent=latent.clone())
+        return vq.forward(latent, B, Hf, Wf, tile16=True)
+
+    @torch.no_grad()
+    def decode_only(self, z_bit_stream, h_bit_stream, img_shape, feat_shape, stack_shape, token_length, z_indices_shape,
+                    clip_stream=None, clip_meta=None):
+        """reference signature (codec_sq_fixbpp.py:881)"""
+        return self.decode_batch([dict(z_bit_stream=z_bit_stream, h_bit_stream=h_bit_stream, img_shape=img_shape,
+                                       feat_shape=feat_shape, stack_shape=stack_shape, token_length=token_length,
+                                       z_indices_shape=z_indices_shape)])
 
     @torch.no_grad()
     def encode_only(self, x):

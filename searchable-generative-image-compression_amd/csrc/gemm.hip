@@ -55,6 +55,12 @@ struct GemmArgs {
   // read / write the [:, a:b] token slice of an (n, L, C) buffer in place (models/cross_blocks.py:87-94)
   int a_seg, a_seg_stride, c_seg, c_seg_stride;
   int vec_epilogue;  // C/R/bias rows are float4-addressable (N, ldc, ldr % 4 == 0, 16-byte aligned bases)
+  // batched GEMM: blockIdx.y = batch index, element strides (0 = shared operand)
+  long sA, sW, sC, sR;
+  // implicit-GEMM 3x3 convolution (stride 1, pad 1): A is a zero-halo NHWC buffer [B, H+2, W+2, C], logical row
+  // m = (b,y,x) of the output, K = 9*C ordered (ky,kx,c); conv_C == 0 disables.  C % 32 == 0 so a 32-wide K
+  // slice never straddles a tap (taming ResnetBlock / Upsample / conv_in / conv_out, model.py:38-137,436-537)
+  int conv_C, conv_H, conv_W;
 };
 
 __device__ __forceinline__ f32x4 ld4_guard(const float *p, bool ok) {
@@ -89,6 +95,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   }
   const int tm = bid / g.tiles_n, tn = bid - tm * g.tiles_n;
   const int m0 = tm * BM, n0 = tn * TBN;
+  {
+    const long bz = blockIdx.y;
+    g.A += bz * g.sA;
+    g.W += bz * g.sW;
+    g.C += bz * g.sC;
+    if (g.R) g.R += bz * g.sR;
+  }
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * (32 * WN);
@@ -105,7 +118,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int am = min(m0 + srow + 32 * i, g.M - 1);
-    const size_t arow = g.a_seg ? (size_t)(am / g.a_seg) * g.a_seg_stride + (am % g.a_seg) : (size_t)am;
+    size_t arow;
+    if (g.conv_C) {  // top-left pixel of the 3x3 patch in the halo buffer
+      const int hw = g.conv_H * g.conv_W, b = am / hw, r = am - b * hw, y = r / g.conv_W, x = r - y * g.conv_W;
+      arow = ((size_t)b * (g.conv_H + 2) + y) * (g.conv_W + 2) + x;
+    } else {
+      arow = g.a_seg ? (size_t)(am / g.a_seg) * g.a_seg_stride + (am % g.a_seg) : (size_t)am;
+    }
     aptr[i] = g.A + arow * g.lda;
   }
 #pragma unroll
@@ -120,8 +139,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   // used for odd K such as the 12-wide decoder embedding).
   auto issue_loads = [&](int k0) {
     if constexpr (!KTAIL) {
+      int ka = k0;
+      if (g.conv_C) {  // wave-uniform: which tap this K slice belongs to
+        const int tap = k0 / g.conv_C, c0 = k0 - tap * g.conv_C, ky = tap / 3, kx = tap - 3 * ky;
+        ka = (ky * (g.conv_W + 2) + kx) * g.conv_C + c0;
+      }
 #pragma unroll
-      for (int i = 0; i < 4; i++) ra[i] = *reinterpret_cast<const f32x4 *>(aptr[i] + k0 + schunk * 4);
+      for (int i = 0; i < 4; i++) ra[i] = *reinterpret_cast<const f32x4 *>(aptr[i] + ka + schunk * 4);
 #pragma unroll
       for (int i = 0; i < NB4; i++) rb[i] = *reinterpret_cast<const f32x4 *>(wptr[i] + k0 + schunk * 4);
     } else {
@@ -263,32 +287,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   }
 }
 
-// C[M,N] = act(A[M,K] @ W[N,K]^T + bias) + R      (nn.Linear / 1x1 conv semantics, all fp32)
-extern "C" int sgic_gemm_f32(const float *d_A, int lda, const float *d_W, int ldw, const float *d_bias,
-                             const float *d_R, int ldr, float *d_C, int ldc, int M, int N, int K, int act,
-                             int a_seg, int a_seg_stride, int c_seg, int c_seg_stride, sgic_stream_t stream) {
-  SGIC_REQUIRE(d_A && d_W && d_C && M > 0 && N > 0 && K > 0, "null/empty");
-  SGIC_REQUIRE((K & 3) == 0 && (lda & 3) == 0 && (ldw & 3) == 0, "K, lda, ldw must be multiples of 4 floats");
-  SGIC_REQUIRE(lda >= K && ldw >= K && ldc >= N && (!d_R || ldr >= N), "leading dimensions");
-  SGIC_REQUIRE(((uintptr_t)d_A & 15) == 0 && ((uintptr_t)d_W & 15) == 0, "A and W must be 16-byte aligned");
-  SGIC_REQUIRE(act >= 0 && act <= ACT_LRELU, "activation");
-  SGIC_REQUIRE(a_seg >= 0 && c_seg >= 0 && (a_seg == 0 || a_seg_stride >= a_seg) && (c_seg == 0 || c_seg_stride >= c_seg),
-               "row segment maps");
+static int gemm_launch(GemmArgs g, int batch, hipStream_t st) {
+  const int M = g.M, N = g.N, K = g.K;
   // Tile choice: 128x128 unless the 128x64 grid fills the last round of workgroups on the 256 CUs clearly
   // better (workgroups are dispatched dynamically, so the makespan is ~ceil(blocks / 256) block-times).
   const int tm = (M + BM - 1) / BM;
   auto eff = [&](int bn) {
-    const double nb = (double)tm * ((N + bn - 1) / bn) / 256.0;
+    const double nb = (double)tm * ((N + bn - 1) / bn) * batch / 256.0;
     return nb / ceil(nb);
   };
   const bool narrow = N <= 64 || eff(64) > eff(128) + 0.04;
-  GemmArgs g{d_A, d_W, d_bias, d_R, d_C, M, N, K, lda, ldw, ldr, ldc, act, tm, narrow ? (N + 63) / 64 : (N + 127) / 128,
-             a_seg, a_seg_stride, c_seg, c_seg_stride, 0};
-  g.vec_epilogue = (N % 4 == 0) && (ldc % 4 == 0) && (((uintptr_t)d_C) & 15) == 0 &&
-                   (!d_R || ((ldr % 4 == 0) && (((uintptr_t)d_R) & 15) == 0)) && (!d_bias || (((uintptr_t)d_bias) & 15) == 0);
+  g.tiles_m = tm;
+  g.tiles_n = narrow ? (N + 63) / 64 : (N + 127) / 128;
   const bool ktail = (K % BK) != 0;
-  const unsigned grid = g.tiles_m * g.tiles_n;
-  hipStream_t st = to_stream(stream);
+  const dim3 grid(g.tiles_m * g.tiles_n, batch);
   if (narrow) {
     if (ktail) gemm_f32_kernel<1, true><<<grid, 256, 0, st>>>(g);
     else gemm_f32_kernel<1, false><<<grid, 256, 0, st>>>(g);
@@ -297,4 +309,63 @@ extern "C" int sgic_gemm_f32(const float *d_A, int lda, const float *d_W, int ld
     else gemm_f32_kernel<2, false><<<grid, 256, 0, st>>>(g);
   }
   return sgic::check_launch("gemm_f32_kernel");
+}
+
+static int gemm_check(const float *d_A, int lda, const float *d_W, int ldw, const float *d_bias, const float *d_R, int ldr,
+                      float *d_C, int ldc, int M, int N, int K, int act) {
+  SGIC_REQUIRE(d_A && d_W && d_C && M > 0 && N > 0 && K > 0, "null/empty");
+  SGIC_REQUIRE((K & 3) == 0 && (lda & 3) == 0 && (ldw & 3) == 0, "K, lda, ldw must be multiples of 4 floats");
+  SGIC_REQUIRE(ldw >= K && ldc >= N && (!d_R || ldr >= N), "leading dimensions");
+  SGIC_REQUIRE(((uintptr_t)d_A & 15) == 0 && ((uintptr_t)d_W & 15) == 0, "A and W must be 16-byte aligned");
+  SGIC_REQUIRE(act >= 0 && act <= ACT_LRELU, "activation");
+  (void)d_bias;
+  return SGIC_OK;
+}
+
+static int vec_ok(const float *d_bias, const float *d_R, int ldr, float *d_C, int ldc, int N, long sC, long sR) {
+  return (N % 4 == 0) && (ldc % 4 == 0) && (((uintptr_t)d_C) & 15) == 0 && (sC % 4 == 0) &&
+         (!d_R || ((ldr % 4 == 0) && (((uintptr_t)d_R) & 15) == 0 && (sR % 4 == 0))) && (!d_bias || (((uintptr_t)d_bias) & 15) == 0);
+}
+
+// C[M,N] = act(A[M,K] @ W[N,K]^T + bias) + R      (nn.Linear / 1x1 conv semantics, all fp32)
+extern "C" int sgic_gemm_f32(const float *d_A, int lda, const float *d_W, int ldw, const float *d_bias,
+                             const float *d_R, int ldr, float *d_C, int ldc, int M, int N, int K, int act,
+                             int a_seg, int a_seg_stride, int c_seg, int c_seg_stride, sgic_stream_t stream) {
+  int rc = gemm_check(d_A, lda, d_W, ldw, d_bias, d_R, ldr, d_C, ldc, M, N, K, act);
+  if (rc) return rc;
+  SGIC_REQUIRE(lda >= K, "lda");
+  SGIC_REQUIRE(a_seg >= 0 && c_seg >= 0 && (a_seg == 0 || a_seg_stride >= a_seg) && (c_seg == 0 || c_seg_stride >= c_seg),
+               "row segment maps");
+  GemmArgs g{d_A, d_W, d_bias, d_R, d_C, M, N, K, lda, ldw, ldr, ldc, act, 0, 0, a_seg, a_seg_stride, c_seg, c_seg_stride,
+             vec_ok(d_bias, d_R, ldr, d_C, ldc, N, 0, 0), 0, 0, 0, 0, 0, 0, 0};
+  return gemm_launch(g, 1, to_stream(stream));
+}
+
+// batch of independent GEMMs with element strides (stride 0 = operand shared by all batches); used for the
+// single-head attention of the VQGAN AttnBlock (model.py:168-192): S_b = Q_b K_b^T, O_b = P_b V_b.
+extern "C" int sgic_gemm_batched_f32(const float *d_A, int lda, long strideA, const float *d_W, int ldw, long strideW,
+                                     const float *d_bias, const float *d_R, int ldr, long strideR, float *d_C, int ldc,
+                                     long strideC, int M, int N, int K, int act, int batch, sgic_stream_t stream) {
+  int rc = gemm_check(d_A, lda, d_W, ldw, d_bias, d_R, ldr, d_C, ldc, M, N, K, act);
+  if (rc) return rc;
+  SGIC_REQUIRE(lda >= K && batch > 0 && batch < 65536 && (strideA & 3) == 0 && (strideW & 3) == 0, "batch/strides");
+  GemmArgs g{d_A, d_W, d_bias, d_R, d_C, M, N, K, lda, ldw, ldr, ldc, act, 0, 0, 0, 0, 0, 0,
+             vec_ok(d_bias, d_R, ldr, d_C, ldc, N, strideC, strideR), strideA, strideW, strideC, strideR, 0, 0, 0};
+  return gemm_launch(g, batch, to_stream(stream));
+}
+
+// 3x3 stride-1 pad-1 convolution as an implicit GEMM over a zero-halo NHWC input [B, H+2, W+2, Cin]:
+// out[(b,y,x), n] = act(sum_{ky,kx,c} in[b, y+ky, x+kx, c] * W[n, (ky*3+kx)*Cin + c] + bias[n]) + R
+extern "C" int sgic_conv3x3_f32(const float *d_in_halo, const float *d_W, const float *d_bias, const float *d_R, int ldr,
+                                float *d_out, int ldc, int B, int H, int W, int Cin, int Cout, int act,
+                                sgic_stream_t stream) {
+  const long Ml = (long)B * H * W;
+  SGIC_REQUIRE(Ml < (1l << 31), "too many pixels");
+  const int M = (int)Ml, K = 9 * Cin;
+  int rc = gemm_check(d_in_halo, Cin, d_W, K, d_bias, d_R, ldr, d_out, ldc, M, Cout, K, act);
+  if (rc) return rc;
+  SGIC_REQUIRE(Cin % BK == 0, "implicit-GEMM conv needs Cin % 32 == 0");
+  GemmArgs g{d_in_halo, d_W, d_bias, d_R, d_out, M, Cout, K, Cin, K, ldr, ldc, act, 0, 0, 0, 0, 0, 0,
+             vec_ok(d_bias, d_R, ldr, d_out, ldc, Cout, 0, 0), 0, 0, 0, 0, Cin, H, W};
+  return gemm_launch(g, 1, to_stream(stream));
 }

@@ -230,6 +230,7 @@ extern "C" int sgic_gated_lrelu(const float *d_x, float *d_out, int M, int C2, s
 // Broadcast column ops on (M, C) rows, vec has `vrows` rows of C and row m uses vec[m % vrows]:
 //   mode 0: y = x * v          (enc_q / dec_q scaling, models/sq_bottleneck.py:111,117; y_hat*q_step)
 //   mode 1: y = x / max(v,0.5) (y / clamp_min(q_step, 0.5), entropy/compression_model.py:325-326)
+//   mode 2: y = x * max(v,0.5) (y_hat * clamp_min(q_step, 0.5), entropy/compression_model.py:355,414)
 // ------------------------------------------------------------------------------------------------
 __global__ void colop_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ v, int ldv, int vrows,
                              float *__restrict__ y, int ldy, long M, int C, int mode) {
@@ -242,14 +243,14 @@ __global__ void colop_kernel(const float *__restrict__ x, int ldx, const float *
     const f32x4 b = reinterpret_cast<const f32x4 *>(v + (m % vrows) * ldv)[c4];
     f32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; e++) o[e] = mode == 0 ? a[e] * b[e] : a[e] / fmaxf(b[e], 0.5f);
+    for (int e = 0; e < 4; e++) o[e] = mode == 0 ? a[e] * b[e] : (mode == 1 ? a[e] / fmaxf(b[e], 0.5f) : a[e] * fmaxf(b[e], 0.5f));
     reinterpret_cast<f32x4 *>(y + m * ldy)[c4] = o;
   }
 }
 
 extern "C" int sgic_colop(const float *d_x, int ldx, const float *d_v, int ldv, int vrows, float *d_y, int ldy, int M,
                           int C, int mode, sgic_stream_t stream) {
-  SGIC_REQUIRE(d_x && d_v && d_y && M > 0 && C > 0 && (C & 3) == 0 && vrows > 0 && (mode == 0 || mode == 1), "args");
+  SGIC_REQUIRE(d_x && d_v && d_y && M > 0 && C > 0 && (C & 3) == 0 && vrows > 0 && (mode >= 0 && mode <= 2), "args");
   SGIC_REQUIRE((ldx & 3) == 0 && (ldv & 3) == 0 && (ldy & 3) == 0, "leading dims multiple of 4");
   colop_kernel<<<ew_grid((long)M * C / 4), 256, 0, to_stream(stream)>>>(d_x, ldx, d_v, ldv, vrows, d_y, ldy, M, C, mode);
   return sgic::check_launch("colop_kernel");

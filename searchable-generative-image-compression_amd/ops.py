@@ -221,3 +221,120 @@ def pack12_batch(idx_i32, B, n):
     out = torch.empty(B, nb, dtype=torch.uint8, device=idx_i32.device)
     call("sgic_pack12_batch", _p(idx_i32), B, n, _p(out))
     return out
+
+
+# ---- decode-side kernels ----
+def gemm_batched(a, lda, sa, w, ldw, sw, out, ldc, sc, M, N, K, batch, bias=None, residual=None, ldr=0, sr=0, act=ACT_NONE):
+    """batch of GEMMs on raw pointers/strides (elements); a, w, out, residual are tensors used as base pointers"""
+    call("sgic_gemm_batched_f32", _p(a), lda, _cl(sa), _p(w), ldw, _cl(sw), _p(bias), _p(residual), ldr, _cl(sr), _p(out), ldc,
+         _cl(sc), M, N, K, act, batch)
+    return out
+
+
+def conv3x3(x_halo, w, bias, B, H, W, Cin, Cout, residual=None, act=ACT_NONE, out=None):
+    """x_halo: zero-halo NHWC buffer (B, H+2, W+2, Cin); w: (Cout, 9*Cin) in (ky,kx,cin) order -> (B*H*W, Cout)"""
+    assert x_halo.is_contiguous() and x_halo.numel() == B * (H + 2) * (W + 2) * Cin
+    assert w.shape == (Cout, 9 * Cin) and w.is_contiguous()
+    if out is None:
+        out = torch.empty(B * H * W, Cout, device=x_halo.device, dtype=torch.float32)
+    out, ldc = _rows(out)
+    ldr = 0
+    if residual is not None:
+        residual, ldr = _rows(residual)
+    call("sgic_conv3x3_f32", _p(x_halo), _p(w), _p(bias), _p(residual), ldr, _p(out), ldc, B, H, W, Cin, Cout, act)
+    return out
+
+
+_GN_WS = {}
+
+
+def groupnorm(x, gamma, beta, B, H, W, swish=True, halo=False, groups=32, eps=1e-6, out=None):
+    """x (B*H*W, C) plain NHWC -> normalised (+swish); halo=True writes the interior of a (B,H+2,W+2,C) buffer
+    whose border must already be zero (pass `out`, or a fresh zero buffer is allocated)."""
+    x, ldx = _rows(x)
+    C = x.shape[1]
+    assert ldx == C
+    dev = x.device
+    key = (str(dev), B, C)
+    if key not in _GN_WS:
+        _GN_WS[key] = (torch.empty(B * 64 * C * 2, dtype=torch.float64, device=dev),
+                       torch.empty(B * groups * 2, dtype=torch.float32, device=dev))
+    ws, stats = _GN_WS[key]
+    if out is None:
+        out = halo_buffer(dev, B, H, W, C) if halo else torch.empty(B * H * W, C, device=dev)
+    call("sgic_groupnorm_nhwc", _p(x), _p(gamma), _p(beta), B, H, W, C, groups, float(eps), int(swish), int(halo), _p(ws),
+         _p(stats), _p(out))
+    return out
+
+
+_HALO = {}
+
+
+def halo_buffer(dev, B, H, W, C):
+    """zero-halo NHWC buffer (B, H+2, W+2, C), cached per shape: producers only ever write the interior, so the
+    border stays zero and no per-call memset is needed.  Uses are strictly sequential on one stream (a halo
+    buffer is consumed by the conv right after it is produced)."""
+    key = (str(dev), B, H, W, C)
+    if key not in _HALO:
+        _HALO[key] = torch.zeros(B, H + 2, W + 2, C, device=dev, dtype=torch.float32)
+    return _HALO[key]
+
+
+def halo_copy(x, B, H, W, C, upsample=False, tile16=False, out=None):
+    s = 2 if upsample else 1
+    if out is None:
+        out = halo_buffer(x.device, B, H * s, W * s, C)
+    call("sgic_halo_copy", _p(x), B, H, W, C, int(upsample), int(tile16), _p(out))
+    return out
+
+
+def softmax_rows(x, L, scale=1.0, out=None):
+    assert x.is_contiguous()
+    M = x.numel() // L
+    if out is None:
+        out = torch.empty_like(x)
+    call("sgic_softmax_rows", _p(x), _p(out), _cl(M), L, float(scale))
+    return out
+
+
+def pixel_shuffle2_tm16(x, B, H, W, C):
+    out = torch.empty(B * 4 * H * W, C, device=x.device, dtype=torch.float32)
+    call("sgic_pixel_shuffle2_tm16", _p(x), B, H, W, C, _p(out))
+    return out
+
+
+def assemble_dec_tokens(emb, cls, mask, pos, latpos, N, P, T, D):
+    out = torch.empty(N * (1 + P + T), D, device=emb.device, dtype=torch.float32)
+    call("sgic_assemble_dec_tokens", _p(emb), _p(cls), _p(mask), _p(pos), _p(latpos), N, P, T, D, _p(out))
+    return out
+
+
+def codebook_gather_norm(idx, codebook, ld=None):
+    M, dim = idx.numel(), codebook.shape[1]
+    ld = ld or dim
+    out = torch.empty(M, ld, device=idx.device, dtype=torch.float32)
+    call("sgic_codebook_gather_norm", _p(idx), _p(codebook), M, dim, ld, _p(out))
+    return out
+
+
+def nhwc3_to_nchw_clamp(x, ld, B, H, W):
+    out = torch.empty(B, 3, H, W, device=x.device, dtype=torch.float32)
+    call("sgic_nhwc3_to_nchw_clamp", _p(x), ld, B, H, W, _p(out))
+    return out
+
+
+def rans_decode_init(streams, cap, off, ln, B):
+    state = torch.zeros(B, 4, dtype=torch.int32, device=streams.device)
+    call("sgic_rans_decode_init_batch", _p(streams), cap, _p(off), _p(ln), B, _p(state))
+    return state
+
+
+def rans_decode_step(table, streams, cap, off, ln, B, state, idx, n, idx_stride, out, out_stride):
+    call("sgic_rans_decode_batch", table, _p(streams), cap, _p(off), _p(ln), B, _p(state), _p(idx), n, idx_stride, _p(out),
+         out_stride)
+
+
+def unpack12_batch(streams_u8, B, n):
+    out = torch.empty(B, n, dtype=torch.int32, device=streams_u8.device)
+    call("sgic_unpack12_batch", _p(streams_u8), B, n, _p(out))
+    return out
