@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--small", action="store_true", help="debug: SMALL/TINY configs (not a valid bench)")
+    ap.add_argument("--mode", choices=["compress", "decompress"], default="compress",
+                    help="compress = the headline metric (BASELINE.json configs[1]); decompress = configs[2]/[4] secondary line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=6)
     args = ap.parse_args()
@@ -96,7 +98,8 @@ def main():
     from sgic_amd.data import synth_images
 
     cfg, clip_cfg = (SMALL, CLIP_TINY) if args.small else (LARGE, CLIP_B32)
-    sd = W.synth_weights(W.encoder_spec(cfg) + W.codec_misc_spec(cfg) + W.bottleneck_spec(cfg), seed=1234)
+    spec = W.full_spec(cfg) if args.mode == "decompress" else W.encoder_spec(cfg) + W.codec_misc_spec(cfg) + W.bottleneck_spec(cfg)
+    sd = W.synth_weights(spec, seed=1234)
     clip_sd = W.synth_weights(W.clip_spec(clip_cfg), seed=4321)
     codec = Codec(sd, cfg, dev)
     codec.hybrid_codec.quantize_feat.force_zero_thres = 0.12
@@ -117,6 +120,13 @@ def main():
         qh = q.cpu().numpy()
         clip_streams = [clipc.compress_codes(qh[b]) for b in range(B)]
         return [(zs[b].tobytes(), h_streams[b], clip_streams[b]) for b in range(B)]
+
+    if args.mode == "decompress":
+        encs = codec.encode_batch(x)          # outside the timed region: the bitstreams to decode
+
+        def step():   # noqa: F811  -- one batch of .c2df payloads -> reconstructed pixels (device-resident fp32)
+            x_hat = codec.decode_batch(encs)
+            return [(b"", b"", b"")] * B if x_hat is not None else None
 
     for _ in range(args.warmup):
         out = step()
@@ -146,7 +156,8 @@ def main():
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         total_bytes = sum(len(a) + len(b) + len(c) for a, b, c in out)
         res = {
-            "metric": "images/sec end-to-end compress (enc+entropy+CLIP) at 256x256",
+            "metric": ("images/sec end-to-end compress (enc+entropy+CLIP) at 256x256" if args.mode == "compress" else
+                       f"images/sec decompress (entropy decode + hybrid decoder + generative decoder) at {S}x{S}"),
             "value": round(world * B * args.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -159,9 +170,10 @@ def main():
                          "avg_launch_us": round(gemm_ms * 1e3 / max(1, n_launch), 2),
                          "gflop_per_launch": round(gemm_flops / max(1, n_launch) / 1e9, 3),
                          "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 4),
-                         "end_to_end_frac": round(GFLOP_PER_IMAGE * B * args.steps / dt / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)},
+                         "end_to_end_frac": round((GFLOP_PER_IMAGE if args.mode == "compress" else 654.3) * (S / 256.0) ** 2 * B *
+                                                  args.steps / dt / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)},
         }
-        if world == 1 and not args.no_cpu_baseline and not args.small:
+        if world == 1 and not args.no_cpu_baseline and not args.small and args.mode == "compress":
             res["cpu_baseline"] = cpu_baseline(sd, clip_sd, cfg, clip_cfg, args.cpu_images)
         print(json.dumps(res), flush=True)
     if world > 1:

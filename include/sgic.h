@@ -197,6 +197,10 @@ int sgic_codebook_gather_norm(const int32_t *d_idx, const float *d_codebook, int
 /* x_hat [(b,y,x), ld>=3] -> clamp(-1,1) -> NCHW (codec_sq_fixbpp.py:901). */
 int sgic_nhwc3_to_nchw_clamp(const float *d_in, int ld, int B, int H, int W, float *d_out, sgic_stream_t stream);
 
+/* exact top-k per row, descending, ties -> lower index (IndexFlatIP.search, search.py:113-120); d_scores
+ * (nq, n) = sgic_gemm_f32(queries, database) and is consumed (taken entries become -inf). */
+int sgic_topk_rows(float *d_scores, int nq, int n, int k, float *d_out_scores, int32_t *d_out_idx, sgic_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,7 +29,7 @@ def get_padding_size(height, width, p=64):
 
 def load_image(path):
     from PIL import Image
-    a = np.asarray(Image.open(path).convert("RGB"), dtype=np.uint8)
+    a = np.array(Image.open(path).convert("RGB"), dtype=np.uint8)
     return torch.from_numpy(a).permute(2, 0, 1).float().div(255.0) * 2.0 - 1.0   # ToTensor, *2-1 (compress.py:161-164)
 
 

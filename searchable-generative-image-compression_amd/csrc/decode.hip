@@ -293,3 +293,47 @@ extern "C" int sgic_nhwc3_to_nchw_clamp(const float *d_in, int ld, int B, int H,
   nhwc3_to_nchw_clamp_kernel<<<ew_grid((long)B * 3 * H * W), 256, 0, to_stream(stream)>>>(d_in, ld, B, H, W, d_out);
   return sgic::check_launch("nhwc3_to_nchw_clamp_kernel");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Exact top-k per row (descending score, ties -> lower index) for IndexFlatIP.search semantics
+// (search.py:113-120): scores [nq, n] come from sgic_gemm_f32(q, db).  One workgroup per query row,
+// k selection passes; k <= 1024, n arbitrary.  Scores are overwritten with -inf as they are taken.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void topk_rows_kernel(float *__restrict__ scores, int n, int k, float *__restrict__ out_s,
+                                                        int *__restrict__ out_i) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  float *row = scores + (long)blockIdx.x * n;
+  for (int j = 0; j < k; j++) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = threadIdx.x; c < n; c += 256) {
+      const float v = row[c];
+      if (v > best || (v == best && c < bi)) best = v, bi = c;
+    }
+    sv[threadIdx.x] = best;
+    si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (threadIdx.x < s) {
+        const float ov = sv[threadIdx.x + s];
+        const int oi = si[threadIdx.x + s];
+        if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) sv[threadIdx.x] = ov, si[threadIdx.x] = oi;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      out_s[(long)blockIdx.x * k + j] = sv[0];
+      out_i[(long)blockIdx.x * k + j] = si[0] == 0x7fffffff ? -1 : si[0];
+      if (si[0] != 0x7fffffff) row[si[0]] = -INFINITY;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int sgic_topk_rows(float *d_scores, int nq, int n, int k, float *d_out_scores, int32_t *d_out_idx,
+                              sgic_stream_t stream) {
+  SGIC_REQUIRE(d_scores && d_out_scores && d_out_idx && nq > 0 && n > 0 && k > 0 && k <= 1024 && k <= n, "args");
+  topk_rows_kernel<<<nq, 256, 0, to_stream(stream)>>>(d_scores, n, k, d_out_scores, d_out_idx);
+  return sgic::check_launch("topk_rows_kernel");
+}

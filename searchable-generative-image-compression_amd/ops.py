@@ -16,7 +16,7 @@ PROFILE = None
 def _rows(t):
     """a 2-D fp32 CUDA view whose last dim is contiguous -> (tensor, leading dimension)"""
     assert t.dim() == 2 and t.stride(1) == 1 and t.dtype == torch.float32 and t.is_cuda, (t.shape, t.stride(), t.dtype)
-    return t, t.stride(0)
+    return t, (t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1]))   # a 1-row view may carry any stride
 
 
 def _p(t):
@@ -338,3 +338,13 @@ def unpack12_batch(streams_u8, B, n):
     out = torch.empty(B, n, dtype=torch.int32, device=streams_u8.device)
     call("sgic_unpack12_batch", _p(streams_u8), B, n, _p(out))
     return out
+
+
+def topk_rows(scores, k):
+    """scores (nq, n) fp32 on device (consumed) -> (top scores (nq,k), indices (nq,k) int32)"""
+    nq, n = scores.shape
+    assert scores.is_contiguous()
+    os_ = torch.empty(nq, k, device=scores.device, dtype=torch.float32)
+    oi = torch.empty(nq, k, device=scores.device, dtype=torch.int32)
+    call("sgic_topk_rows", _p(scores), nq, n, k, _p(os_), _p(oi))
+    return os_, oi

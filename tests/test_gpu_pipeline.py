@@ -1,0 +1,50 @@
+"""GPU: the drivers end to end on a small synthetic corpus (SMALL/TINY architectures): compress.py ->
+.c2df + clip_vecs + FAISS index -> search (top-k parity vs numpy exact search) -> decompress.py -> PNGs."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_compress_search_decompress_cli(tmp_path):
+    from PIL import Image
+    import sgic_amd  # noqa
+    from sgic_amd import compress, decompress, search
+    from sgic_amd.data import synth_images
+    from sgic_amd.faiss_io import read_index_flat_ip
+    from sgic_amd.filemaker import unpack_c2df
+    src = tmp_path / "imgs"
+    src.mkdir()
+    sizes = [(256, 256)] * 5 + [(200, 300)] * 2 + [(512, 256)]
+    for i, (h, w) in enumerate(sizes):
+        x = synth_images(1, 256 * ((h + 255) // 256), 256 * ((w + 255) // 256), 100 + i)[0, :, :h, :w]
+        Image.fromarray(((x * 0.5 + 0.5) * 255).round().byte().permute(1, 2, 0).numpy()).save(src / f"im{i:02d}.png")
+    out = tmp_path / "out"
+    assert compress.main(["--dataset_dir", str(src), "--save_dir", str(out), "--small", "--batch_size", "4"]) == 0
+    files = sorted(os.listdir(out / "bitstreams"))
+    assert files == [f"im{i:02d}.c2df" for i in range(len(sizes))]
+    enc, hdr = unpack_c2df(out / "bitstreams" / "im05.c2df")
+    assert hdr["image_hw"] == [200, 300] and hdr["padding"] == [0, 212, 0, 56] and hdr["version"] == 2
+    assert list(enc.keys()) == ["z_bit_stream", "h_bit_stream", "img_shape", "feat_shape", "stack_shape", "token_length",
+                                "z_indices_shape", "clip_stream", "clip_meta"]
+    vecs = read_index_flat_ip(str(out / "faiss" / "index.faiss"))
+    ids = (out / "faiss" / "ids.txt").read_text().splitlines()
+    assert vecs.shape == (len(sizes), 64) and len(ids) == len(sizes)
+    for i in range(len(sizes)):
+        v = np.load(out / "clip_vecs" / f"im{i:02d}.npy")
+        assert np.allclose(vecs[i], v / (np.linalg.norm(v) + 1e-12), atol=1e-6)
+    # query-c2df: the embedded u8 code of image 3 must retrieve image 3 first; GPU top-k == numpy exact search
+    q, _ = search.decode_clip_from_c2df(out / "bitstreams" / "im03.c2df")
+    s, i = search.search_gpu(q[None], vecs, 5)
+    ref = np.argsort(-(q[None] @ vecs.T), axis=1, kind="stable")[:, :5]
+    assert i[0, 0] == 3 and np.array_equal(i, ref)
+    assert np.allclose(s[0], (q[None] @ vecs.T)[0, ref[0]], atol=1e-5)
+    # decompress
+    assert decompress.main(["--dataset_dir", str(out / "bitstreams"), "--save_dir", str(out), "--small"]) == 0
+    for i, (h, w) in enumerate(sizes):
+        im = Image.open(out / "results" / f"im{i:02d}.png")
+        assert im.size == (w, h)
