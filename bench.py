@@ -161,8 +161,11 @@ def main():
             "value": round(world * B * args.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: batch={B} {S}x{S} encoder+entropy+CLIP compress per GPU, "
-                                   f"{'SMALL debug model' if args.small else 'TiTok ViT-L hybrid encoder + ViT-B/32 CLIP'}, synthetic weights",
+            "config": {"workload": (f"configs[1]: batch={B} {S}x{S} encoder+entropy+CLIP compress per GPU, "
+                                    f"{'SMALL debug model' if args.small else 'TiTok ViT-L hybrid encoder + ViT-B/32 CLIP'}, synthetic weights")
+                       if args.mode == "compress" else
+                       (f"configs[2]: batch={B} {S}x{S} decompress per GPU (rANS decode chain + hybrid decoder + FeatMerge + "
+                        f"taming VQGAN decoder), {'SMALL debug model' if args.small else 'production architecture'}, synthetic weights"),
                        "global_batch": world * B, "bytes_per_image": round(total_bytes / B, 1)},
             "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,

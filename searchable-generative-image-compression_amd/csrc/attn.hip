@@ -34,14 +34,17 @@ struct AttnArgs {
   const float *bias;    // [nvar][L][L] additive bias or null
   const int *biasvar;   // [nseq] variant index or null (=> variant 0)
   float scale;
+  int nwaves, qblocks;
 };
 
-__global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs a) {
+// blockDim.x = 64 * a.nwaves; one workgroup covers 32*nwaves query rows of one (sequence, head); qblocks
+// workgroups cover the sequence.  The host picks nwaves so that padding waste is small (L=289 -> 1 x 10 waves,
+// L=545 -> 2 x 9, L=256 -> 1 x 8) and K/V are staged once per (sequence, head) where possible.
+__global__ __launch_bounds__(640) void attn_f32_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float sK[AT_KT * AT_LDK];
   __shared__ __attribute__((aligned(16))) float sV[AT_KT * AT_LDV];
-  __shared__ int sRow[AT_KT];
 
-  const int qblocks = (a.L + 127) / 128;
+  const int qblocks = a.qblocks, nthreads = blockDim.x;
   int bid = blockIdx.x;
   const int qb = bid % qblocks;
   bid /= qblocks;
@@ -50,7 +53,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, lh = lane >> 5;
-  const int q_tok = qb * 128 + wave * 32 + lq;  // this lane's query token
+  const int q_tok = (qb * a.nwaves + wave) * 32 + lq;  // this lane's query token
   const bool q_ok = q_tok < a.L;
   const int q_tok_c = q_ok ? q_tok : a.L - 1;
   const long q_row = a.rowmap ? a.rowmap[(long)seq * a.L + q_tok_c] : (long)seq * a.L + q_tok_c;
@@ -79,30 +82,48 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs a) {
     bias_base = a.bias + ((long)var * a.L + q_tok_c) * a.L;
   }
 
+  // K/V staging: 32 keys x 16 float4 per operand = 512 float4 each; thread t stages float4 index t (and
+  // t + nthreads if needed).  Loads are unconditional: keys past L are clamped to the last token -- their
+  // scores are forced to -inf below, so P = 0 and the (finite) clamped K/V values never contribute.
+  const int nst = (512 + nthreads - 1) / nthreads;  // 1 or 2
+  f32x4 rk[2], rv[2];
+  auto issue_stage = [&](int key0) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      if (i < nst) {
+        const int f = tid + nthreads * i;
+        if (f < 512) {
+          const int kr = f >> 4, c4 = f & 15;
+          const int tok = min(key0 + kr, a.L - 1);
+          const long row = a.rowmap ? a.rowmap[(long)seq * a.L + tok] : (long)seq * a.L + tok;
+          rk[i] = *reinterpret_cast<const f32x4 *>(a.k + row * a.ldk + hc + c4 * 4);
+          rv[i] = *reinterpret_cast<const f32x4 *>(a.v + row * a.ldv + hc + c4 * 4);
+        }
+      }
+    }
+  };
+  auto store_stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      if (i < nst) {
+        const int f = tid + nthreads * i;
+        if (f < 512) {
+          const int kr = f >> 4, c4 = f & 15;
+          *reinterpret_cast<f32x4 *>(&sK[kr * AT_LDK + c4 * 4]) = rk[i];
+          *reinterpret_cast<f32x4 *>(&sV[kr * AT_LDV + c4 * 4]) = rv[i];
+        }
+      }
+    }
+  };
+
   const int ntiles = (a.L + AT_KT - 1) / AT_KT;
+  issue_stage(0);
   for (int kt = 0; kt < ntiles; ++kt) {
     const int key0 = kt * AT_KT;
     __syncthreads();  // previous tile fully consumed
-    if (tid < AT_KT) {
-      const int tok = key0 + tid;
-      sRow[tid] = tok < a.L ? (int)(a.rowmap ? a.rowmap[(long)seq * a.L + tok] : (long)seq * a.L + tok) : -1;
-    }
+    store_stage();
     __syncthreads();
-    {  // stage K and V: 32 keys x 16 float4 each = 512 float4 per operand, 2 per thread
-#pragma unroll
-      for (int i = 0; i < 2; i++) {
-        const int f = tid + 256 * i, kr = f >> 4, c4 = f & 15;
-        const int row = sRow[kr];
-        f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-        if (row >= 0) {
-          kv = *reinterpret_cast<const f32x4 *>(a.k + (long)row * a.ldk + hc + c4 * 4);
-          vv = *reinterpret_cast<const f32x4 *>(a.v + (long)row * a.ldv + hc + c4 * 4);
-        }
-        *reinterpret_cast<f32x4 *>(&sK[kr * AT_LDK + c4 * 4]) = kv;
-        *reinterpret_cast<f32x4 *>(&sV[kr * AT_LDV + c4 * 4]) = vv;
-      }
-    }
-    __syncthreads();
+    if (kt + 1 < ntiles) issue_stage(key0 + AT_KT);  // next tile's loads fly during this tile's 64 MFMAs
 
     // ---- S^T[key][q] = sum_d K[key][d] * Q[q][d] ----
     f32x16 s;
@@ -118,16 +139,10 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs a) {
     if (bias_base) {
 #pragma unroll
       for (int g4 = 0; g4 < 4; g4++) {
-        const int kb = key0 + 8 * g4 + 4 * lh;
-        if (kb + 3 < a.L) {
-          const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias_base + kb);
+        const int kb = min(key0 + 8 * g4 + 4 * lh, a.L - 4);  // L % 4 == 0 with a bias; clamped reads are masked below
+        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias_base + kb);
 #pragma unroll
-          for (int t = 0; t < 4; t++) s[g4 * 4 + t] += b4[t];
-        } else {
-#pragma unroll
-          for (int t = 0; t < 4; t++)
-            if (kb + t < a.L) s[g4 * 4 + t] += bias_base[kb + t];
-        }
+        for (int t = 0; t < 4; t++) s[g4 * 4 + t] += b4[t];
       }
     }
     if (key0 + AT_KT > a.L) {
@@ -143,7 +158,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs a) {
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx);
     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // whole row masked so far
-    const float alpha = expf(m_run - m_use);               // m_run = -inf -> 0
+    const float alpha = expf(m_run - m_use);                 // m_run = -inf -> 0
     float psum = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; e++) {
@@ -189,8 +204,12 @@ extern "C" int sgic_attention_f32(const float *d_q, int ldq, const float *d_k, i
   SGIC_REQUIRE(ldq >= nheads * 64 && ldk >= nheads * 64 && ldv >= nheads * 64 && ldo >= nheads * 64, "head_dim is 64");
   SGIC_REQUIRE((((uintptr_t)d_q | (uintptr_t)d_k | (uintptr_t)d_v | (uintptr_t)d_out) & 15) == 0, "16-byte alignment");
   SGIC_REQUIRE(!d_bias || (L & 3) == 0, "bias needs L % 4 == 0");
-  AttnArgs a{d_q, d_k, d_v, d_out, ldq, ldk, ldv, ldo, L, nseq, nheads, d_rowmap, d_bias, d_biasvar, scale};
-  const long grid = (long)nseq * nheads * ((L + 127) / 128);
-  attn_f32_kernel<<<(unsigned)grid, 256, 0, to_stream(stream)>>>(a);
+  const int rows32 = (L + 31) / 32;             // 32-row wave slices needed
+  const int qblocks = (rows32 + 9) / 10;        // at most 10 waves (640 threads) per workgroup
+  int nwaves = (rows32 + qblocks - 1) / qblocks;
+  if (nwaves < 4) nwaves = 4;                   // >= 256 threads so the 2-slot K/V staging covers a tile
+  AttnArgs a{d_q, d_k, d_v, d_out, ldq, ldk, ldv, ldo, L, nseq, nheads, d_rowmap, d_bias, d_biasvar, scale, nwaves, qblocks};
+  const long grid = (long)nseq * nheads * qblocks;
+  attn_f32_kernel<<<(unsigned)grid, 64 * nwaves, 0, to_stream(stream)>>>(a);
   return sgic::check_launch("attn_f32_kernel");
 }
