@@ -112,6 +112,11 @@ int sgic_gemm_f32(const float *d_A, int lda, const float *d_W, int ldw, const fl
                   int ldr, float *d_C, int ldc, int M, int N, int K, int act, int a_seg, int a_seg_stride,
                   int c_seg, int c_seg_stride, sgic_stream_t stream);
 
+/* Tile override for the following GEMM / conv launches of this process: 0 = built-in heuristic, 1 = 128x128,
+ * 2 = 128x64 workgroup tiles.  Results are bitwise identical for every choice (the k order is fixed); the host
+ * autotuner (sgic_amd.ops) uses it to pick the faster tile per GEMM shape. */
+int sgic_gemm_set_tile(int mode);
+
 /* Row LayerNorm, biased variance, eps inside sqrt, optional fused SiLU (act = SGIC_ACT_SILU); rows of x
  * and y addressed through the same kind of segment map (titok/blocks.py:36,42,
  * blocks/swin_transformer.py:135,142, blocks/conv_blocks.py:62, models/cross_blocks.py:62,67). */

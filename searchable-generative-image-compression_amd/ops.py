@@ -31,6 +31,33 @@ def empty(*shape, like=None, dtype=torch.float32, device=None):
     return torch.empty(*shape, dtype=dtype, device=like.device if like is not None else device)
 
 
+# Per-shape tile autotuning ("measure, don't guess"): the first time a GEMM shape is seen, both workgroup tiles
+# are timed with HIP events on the launch stream and the faster one is remembered.  Both tiles give bitwise
+# identical results, so tuning never changes an output.  AUTOTUNE = False uses the built-in heuristic.
+AUTOTUNE = True
+_TILE = {}
+
+
+def _tune(key, launch):
+    from ._lib import lib
+    best, best_t = 0, None
+    for mode in (1, 2):
+        lib.sgic_gemm_set_tile(mode)
+        launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            launch()
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1)
+        if best_t is None or t < best_t:
+            best, best_t = mode, t
+    lib.sgic_gemm_set_tile(0)
+    _TILE[key] = best
+    return best
+
+
 def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(0, 0), c_seg=(0, 0)):
     """out[M,N] = act(a[M,K] @ w[N,K]^T + bias) + residual.  a_seg/c_seg = (seg, seg_stride) row maps:
     logical row m of A (resp. C) lives at physical row (m // seg) * seg_stride + m % seg."""
@@ -53,11 +80,31 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(
         assert residual.shape[1] == N and residual.shape[0] >= M
     if bias is not None:
         assert bias.shape == (N,) and bias.is_contiguous()
+    def launch():
+        call("sgic_gemm_f32", _p(a), lda, _p(w), ldw, _p(bias), _p(residual), ldr, _p(out), ldc, M, N, K, act,
+             a_seg[0], a_seg[1], c_seg[0], c_seg[1])
+
+    tile = 0
+    if AUTOTUNE and M * N >= (1 << 20):
+        key = (M, N, K, residual is not None, act, str(a.device))
+        tile = _TILE.get(key)
+        if tile is None:
+            # in-place residual GEMMs (out is residual) are not idempotent: save / restore the buffer around tuning
+            if residual is not None and out.data_ptr() == residual.data_ptr():
+                saved = out.clone()
+                tile = _tune(key, launch)
+                out.copy_(saved)
+            else:
+                tile = _tune(key, launch)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call("sgic_gemm_f32", _p(a), lda, _p(w), ldw, _p(bias), _p(residual), ldr, _p(out), ldc, M, N, K, act,
-         a_seg[0], a_seg[1], c_seg[0], c_seg[1])
+    if tile:
+        from ._lib import lib
+        lib.sgic_gemm_set_tile(tile)
+    launch()
+    if tile:
+        lib.sgic_gemm_set_tile(0)
     if PROFILE is not None:
         e1.record()
         PROFILE.append((2.0 * M * N * K, e0, e1))
