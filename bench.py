@@ -110,16 +110,59 @@ def main():
     x = synth_images(B, S, S, seed=1000 + rank).to(dev)   # inputs resident in HBM before the timed region
     gathered = torch.empty(world * B, clip_cfg.embed_dim, device=dev) if world > 1 else None
 
-    def step():
-        r = codec.encode_device(x)
+    # Two-deep software pipeline over steps: the GPU work of step i (encoder, entropy coding, CLIP, async D2H into
+    # pinned buffers) is enqueued before the host finishes step i-1 (slice the streams, zstd the CLIP codes), so
+    # the host-side byte work hides under the GPU.  Every step still ends as 32 x (z, h, clip) host byte strings
+    # inside the timed region.  The rANS kernel (serial, ~1 ms) runs on a side HIP stream under the CLIP tower.
+    side = torch.cuda.Stream(device=dev)
+    ntok = cfg.num_latent_tokens * (S // cfg.crop_size) ** 2
+    cap = 2 * (4 * (cfg.embed_dim // 4) * (S // 32) ** 2) + 64
+    from sgic_amd._lib import lib as _sl
+    pinned = [dict(hs=torch.empty(B, cap, dtype=torch.uint8).pin_memory(), meta=torch.empty(3, B, dtype=torch.int32).pin_memory(),
+                   zs=torch.empty(B, _sl.sgic_pack12_size(ntok), dtype=torch.uint8).pin_memory(),
+                   q=torch.empty(B, clip_cfg.embed_dim, dtype=torch.uint8).pin_memory()) for _ in range(2)]
+
+    def enqueue(slot):
+        r = codec.encode_device(x, side_stream=side)
         unit, q = clipc.batch_to_codes(x)
         if world > 1:
             dist.all_gather_into_tensor(gathered, unit)   # CLIP vectors for the FAISS index (RCCL over xGMI)
-        h_streams = codec.bottleneck.streams_to_host(r["hs"], r["hmeta"])
-        zs = r["zs"].cpu().numpy()
-        qh = q.cpu().numpy()
-        clip_streams = [clipc.compress_codes(qh[b]) for b in range(B)]
-        return [(zs[b].tobytes(), h_streams[b], clip_streams[b]) for b in range(B)]
+        torch.cuda.current_stream().wait_stream(side)
+        p = pinned[slot]
+        p["hs"].copy_(r["hs"], non_blocking=True)
+        p["meta"].copy_(r["hmeta"], non_blocking=True)
+        p["zs"].copy_(r["zs"], non_blocking=True)
+        p["q"].copy_(q, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return p, ev, r
+
+    def finalize(h):
+        p, ev, _ = h
+        ev.synchronize()
+        meta = p["meta"].numpy()
+        if int(np.abs(meta[2]).sum()) != 0:
+            raise RuntimeError(f"rANS encode error codes {meta[2].tolist()}")
+        hs, zs, qh = p["hs"].numpy(), p["zs"].numpy(), p["q"].numpy()
+        return [(zs[b].tobytes(), hs[b, meta[0, b]:meta[0, b] + meta[1, b]].tobytes(), clipc.compress_codes(qh[b]))
+                for b in range(B)]
+
+    class _Pipe:
+        prev, i, last = None, 0, None
+
+    def step():
+        cur = enqueue(_Pipe.i & 1)
+        _Pipe.i += 1
+        if _Pipe.prev is not None:
+            _Pipe.last = finalize(_Pipe.prev)
+        _Pipe.prev = cur
+        return _Pipe.last
+
+    def drain():
+        if _Pipe.prev is not None:
+            _Pipe.last = finalize(_Pipe.prev)
+            _Pipe.prev = None
+        return _Pipe.last
 
     if args.mode == "decompress":
         encs = codec.encode_batch(x)          # outside the timed region: the bitstreams to decode
@@ -128,8 +171,14 @@ def main():
             x_hat = codec.decode_batch(encs)
             return [(b"", b"", b"")] * B if x_hat is not None else None
 
-    for _ in range(args.warmup):
-        out = step()
+    if args.mode == "compress":
+        for _ in range(args.warmup):
+            step()
+        out = drain()
+    else:
+        drain = lambda: None   # noqa: E731
+        for _ in range(args.warmup):
+            out = step()
 
     def sync():
         if world > 1:
@@ -141,6 +190,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    out = drain() or out      # the last step's host work is inside the timed region too
     sync()
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None

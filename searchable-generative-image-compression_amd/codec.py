@@ -57,8 +57,11 @@ class Codec:
     def eval(self):
         return self
 
-    def encode_device(self, x):
-        """x (B,3,H,W) on device, in [-1,1], H,W multiples of 256 -> device-side results"""
+    def encode_device(self, x, side_stream=None):
+        """x (B,3,H,W) on device, in [-1,1], H,W multiples of 256 -> device-side results.
+        With `side_stream`, the rANS kernel (a serial recurrence: one lane per image, ~1 ms) is launched on that
+        HIP stream so the caller's next kernels (the CLIP tower) overlap it; join with
+        torch.cuda.current_stream().wait_stream(side_stream) before reading hs / hmeta."""
         cfg = self.cfg
         B, _, H, W = x.shape
         assert H % cfg.crop_size == 0 and W % cfg.crop_size == 0, "pad to a multiple of 256 first (compress.py:258)"
@@ -67,7 +70,22 @@ class Codec:
         ntok = cfg.num_latent_tokens * nH * nW
         zs = ops.pack12_batch(vq, B, ntok)
         hh, ww = H // (2 * cfg.patch_size), W // (2 * cfg.patch_size)
-        out, meta, sym, idx = self.bottleneck.compress(h, B, hh, ww)
+        bn = self.bottleneck
+        if bn.tables is None:
+            raise RuntimeError("call hybrid_codec.quantize_feat.update(force=True) first (compress.py:239)")
+        y = bn.analysis(h, B, hh, ww)
+        sym, idx, _, _ = bn.quantise(y, B, hh, ww)
+        n = 4 * (bn.Q // 4) * hh * ww
+        if side_stream is not None:
+            side_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side_stream):
+                out, meta = ops.rans_encode_batch(bn.tables.handles[bn.group], sym, idx, B, n)
+            for t in (sym, idx):
+                t.record_stream(side_stream)
+            for t in (out, meta):
+                t.record_stream(torch.cuda.current_stream())
+        else:
+            out, meta = ops.rans_encode_batch(bn.tables.handles[bn.group], sym, idx, B, n)
         return dict(z=z, h=h, vq=vq, zs=zs, hs=out, hmeta=meta, sym=sym, idx=idx, stack=(nH, nW), feat_hw=(hh, ww), ntok=ntok)
 
     def encode_batch(self, x):
