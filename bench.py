@@ -203,8 +203,26 @@ def main():
         gemm_flops = sum(p[0] for p in prof)
         gemm_ms = sum(p[1].elapsed_time(p[2]) for p in prof)
         n_launch = len(prof)
+        if os.environ.get("SGIC_BENCH_SHAPES"):   # per-shape breakdown of the dominant kernel (stderr)
+            agg = {}
+            for fl, a_, b_, key in prof:
+                t_ = a_.elapsed_time(b_)
+                v = agg.setdefault(key, [0.0, 0.0, 0])
+                v[0] += fl; v[1] += t_; v[2] += 1
+            for key, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                tile = ops._TILE.get(key + (str(dev),))
+                print(f"[gemm] M,N,K,res,act={key} tile={tile} calls={v[2]} total_ms={v[1]:.2f} share={v[1]/gemm_ms:.3f} "
+                      f"TF={v[0]/v[1]/1e9:.1f}", file=sys.stderr)
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         total_bytes = sum(len(a) + len(b) + len(c) for a, b, c in out)
+        # HBM-side bytes per GEMM launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2-corrected + WRITE_SIZE,
+        # MI355X_MICROARCH.md) committed under profiles/; PMC counters cannot be read live from inside this process.
+        traffic = None
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_gemm_summary.json")))
+            traffic = int((pj["hbm_fetch_MB_per_launch_x2_corrected"] + pj["hbm_write_MB_per_launch"]) * 1e6)
+        except Exception:
+            pass
         res = {
             "metric": ("images/sec end-to-end compress (enc+entropy+CLIP) at 256x256" if args.mode == "compress" else
                        f"images/sec decompress (entropy decode + hybrid decoder + generative decoder) at {S}x{S}"),
@@ -218,7 +236,8 @@ def main():
                         f"taming VQGAN decoder), {'SMALL debug model' if args.small else 'production architecture'}, synthetic weights"),
                        "global_batch": world * B, "bytes_per_image": round(total_bytes / B, 1)},
             "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic if args.mode == "compress" else None,
+                         "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/round1_pmc_gemm_summary.json)",
                          "launches_per_step": n_launch // max(1, args.steps),
                          "avg_launch_us": round(gemm_ms * 1e3 / max(1, n_launch), 2),
                          "gflop_per_launch": round(gemm_flops / max(1, n_launch) / 1e9, 3),

@@ -99,14 +99,18 @@ __device__ __forceinline__ f32x4 ld4_guard(const float *p, bool ok) {
 //   sub-steps 0..2 : MFMAs on the current buffer, fragments of sub-step s+1 prefetched (2 register sets)
 //   barrier        : tile kt+1 visible, nobody reads the current buffer any more
 //   sub-step 3     : prefetch sub-step 0 of tile kt+1 from the other buffer, then the last 16/8 MFMAs
-template <int WN, bool KTAIL>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
+template <int WN, bool KTAIL, int NBUF>
+__global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_f32_kernel(GemmArgs g) {
   constexpr int TBN = 64 * WN;          // workgroup tile N
   constexpr int NB4 = TBN / 32;         // float4 staged per thread for the W tile (TBN rows x 8 chunks / 256)
   // one LDS array: [A buf0 | A buf1 | W buf0 | W buf1]; the epilogue reuses it as 4 per-wave transpose tiles
-  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + TBN) * LDS_LD];
+  // NBUF = 2: double-buffered LDS, one barrier per K-step, 2 workgroups per CU.  NBUF = 1: single buffer, two
+  // barriers per K-step but 3 workgroups per CU (more waves to cover each other's barrier / epilogue phases).
+  constexpr int EP_FLOATS = 4 * 32 * 32 * WN;  // epilogue transpose slices of the 4 waves (32 rows at a time)
+  constexpr int ST_FLOATS = NBUF * (BM + TBN) * LDS_LD;
+  __shared__ __attribute__((aligned(16))) float smem[ST_FLOATS > EP_FLOATS ? ST_FLOATS : EP_FLOATS];
   float(*sA)[BM * LDS_LD] = reinterpret_cast<float(*)[BM * LDS_LD]>(smem);
-  float(*sB)[TBN * LDS_LD] = reinterpret_cast<float(*)[TBN * LDS_LD]>(smem + 2 * BM * LDS_LD);
+  float(*sB)[TBN * LDS_LD] = reinterpret_cast<float(*)[TBN * LDS_LD]>(smem + NBUF * BM * LDS_LD);
 
   // ---- XCD-aware bijective remap: hardware deals consecutive block ids round-robin over 8 XCDs ----
   const int nwg = g.tiles_m * g.tiles_n;
@@ -234,28 +238,49 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 
   const int nk = (g.K + BK - 1) / BK;
   Frag f0, f1;
-  issue_loads(0);
-  store_lds(0);
-  if (nk > 1) issue_loads(BK);
-  __syncthreads();
-  read_frag(f0, 0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1, nxt = cur ^ 1;
-    if (kt + 1 < nk) {
-      store_lds(nxt);  // tile kt+1; buffer nxt was last read before the previous step's barrier
-      if (kt + 2 < nk) issue_loads((kt + 2) * BK);
+  if constexpr (NBUF == 2) {
+    issue_loads(0);
+    store_lds(0);
+    if (nk > 1) issue_loads(BK);
+    __syncthreads();
+    read_frag(f0, 0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1, nxt = cur ^ 1;
+      if (kt + 1 < nk) {
+        store_lds(nxt);  // tile kt+1; buffer nxt was last read before the previous step's barrier
+        if (kt + 2 < nk) issue_loads((kt + 2) * BK);
+      }
+      read_frag(f1, cur, 1);
+      mfma_frag(f0);
+      read_frag(f0, cur, 2);
+      mfma_frag(f1);
+      read_frag(f1, cur, 3);
+      mfma_frag(f0);
+      // one barrier per K-step: LDS traffic only (the staged global loads stay in flight across it)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 1 < nk) read_frag(f0, nxt, 0);
+      mfma_frag(f1);
     }
-    read_frag(f1, cur, 1);
-    mfma_frag(f0);
-    read_frag(f0, cur, 2);
-    mfma_frag(f1);
-    read_frag(f1, cur, 3);
-    mfma_frag(f0);
-    // one barrier per K-step: LDS traffic only (the staged global loads stay in flight across it)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 1 < nk) read_frag(f0, nxt, 0);
-    mfma_frag(f1);
+  } else {
+    issue_loads(0);
+    for (int kt = 0; kt < nk; ++kt) {
+      store_lds(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 1 < nk) issue_loads((kt + 1) * BK);  // in flight during the MFMA phase below
+      read_frag(f0, 0, 0);
+      read_frag(f1, 0, 1);
+      mfma_frag(f0);
+      read_frag(f0, 0, 2);
+      mfma_frag(f1);
+      read_frag(f1, 0, 3);
+      mfma_frag(f0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // everyone done reading before the next store
+      mfma_frag(f1);
+    }
+    __syncthreads();  // epilogue reuses the staging LDS
   }
 
   // ---- epilogue.  Accumulator layout: D[row = (e&3) + 8*(e>>2) + 4*lhalf][col = lrow] ----
@@ -266,33 +291,34 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     constexpr int TW = 32 * WN;            // wave tile width (floats)
     constexpr int LPR = TW / 4;            // lanes per row (float4 each)
     constexpr int RPI = 64 / LPR;          // rows per store instruction
-    float *ep = smem + wave * (64 * TW);
+    float *ep = smem + wave * (32 * TW);   // 32 x TW floats per wave, used twice (upper / lower 32 rows)
+    const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
+    const int n = n0 + wn + c4;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias && n < g.N) bv = *reinterpret_cast<const f32x4 *>(g.bias + n);
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 2; i++) {
 #pragma unroll
       for (int j = 0; j < WN; j++)
 #pragma unroll
-        for (int e = 0; e < 16; e++)
-          ep[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf) * TW + j * 32 + lrow] = acc[i][j][e];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
-    const int n = n0 + wn + c4;
-    if (n < g.N) {  // N % 4 == 0 in this path, so a float4 is all-in or all-out
-      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      if (g.bias) bv = *reinterpret_cast<const f32x4 *>(g.bias + n);
+        for (int e = 0; e < 16; e++) ep[((e & 3) + 8 * (e >> 2) + 4 * lhalf) * TW + j * 32 + lrow] = acc[i][j][e];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (n < g.N) {  // N % 4 == 0 in this path, so a float4 is all-in or all-out
 #pragma unroll
-      for (int it = 0; it < 64 / RPI; ++it) {
-        const int r = it * RPI + r0;
-        const int m = m0 + wm + r;
-        if (m < g.M) {
-          f32x4 v = *reinterpret_cast<const f32x4 *>(ep + r * TW + c4);
+        for (int it = 0; it < 32 / RPI; ++it) {
+          const int r = it * RPI + r0;
+          const int m = m0 + wm + i * 32 + r;
+          if (m < g.M) {
+            f32x4 v = *reinterpret_cast<const f32x4 *>(ep + r * TW + c4);
 #pragma unroll
-          for (int t = 0; t < 4; t++) v[t] = apply_act(v[t] + bv[t], g.act);
-          if (g.R) v += *reinterpret_cast<const f32x4 *>(g.R + (size_t)m * g.ldr + n);
-          const size_t crow = g.c_seg ? (size_t)(m / g.c_seg) * g.c_seg_stride + (m % g.c_seg) : (size_t)m;
-          *reinterpret_cast<f32x4 *>(g.C + crow * g.ldc + n) = v;
+            for (int t = 0; t < 4; t++) v[t] = apply_act(v[t] + bv[t], g.act);
+            if (g.R) v += *reinterpret_cast<const f32x4 *>(g.R + (size_t)m * g.ldr + n);
+            const size_t crow = g.c_seg ? (size_t)(m / g.c_seg) * g.c_seg_stride + (m % g.c_seg) : (size_t)m;
+            *reinterpret_cast<f32x4 *>(g.C + crow * g.ldc + n) = v;
+          }
         }
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS reads done before the slice is overwritten
     }
     return;
   }
@@ -319,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 
 static int g_tile_override = 0;  // 0 = heuristic, 1 = 128x128, 2 = 128x64 (set by the host-side autotuner)
 extern "C" int sgic_gemm_set_tile(int mode) {
-  if (mode < 0 || mode > 2) return SGIC_EINVAL;
+  if (mode < 0 || mode > 4) return SGIC_EINVAL;
   g_tile_override = mode;
   return SGIC_OK;
 }
@@ -334,17 +360,23 @@ static int gemm_launch(GemmArgs g, int batch, hipStream_t st) {
     return nb / ceil(nb);
   };
   bool narrow = N <= 64 || eff(64) > eff(128) + 0.04;
-  if (g_tile_override) narrow = (g_tile_override == 2);
+  bool single = false;  // tile modes: 1 = 128x128 / 2 buffers, 2 = 128x64 / 2 buffers, 3 = 128x128 / 1 buffer, 4 = 128x64 / 1 buffer
+  if (g_tile_override) {
+    narrow = (g_tile_override == 2 || g_tile_override == 4);
+    single = g_tile_override >= 3;
+  }
   g.tiles_m = tm;
   g.tiles_n = narrow ? (N + 63) / 64 : (N + 127) / 128;
   const bool ktail = (K % BK) != 0;
   const dim3 grid(g.tiles_m * g.tiles_n, batch);
   if (narrow) {
-    if (ktail) gemm_f32_kernel<1, true><<<grid, 256, 0, st>>>(g);
-    else gemm_f32_kernel<1, false><<<grid, 256, 0, st>>>(g);
+    if (ktail) gemm_f32_kernel<1, true, 2><<<grid, 256, 0, st>>>(g);
+    else if (single) gemm_f32_kernel<1, false, 1><<<grid, 256, 0, st>>>(g);
+    else gemm_f32_kernel<1, false, 2><<<grid, 256, 0, st>>>(g);
   } else {
-    if (ktail) gemm_f32_kernel<2, true><<<grid, 256, 0, st>>>(g);
-    else gemm_f32_kernel<2, false><<<grid, 256, 0, st>>>(g);
+    if (ktail) gemm_f32_kernel<2, true, 2><<<grid, 256, 0, st>>>(g);
+    else if (single) gemm_f32_kernel<2, false, 1><<<grid, 256, 0, st>>>(g);
+    else gemm_f32_kernel<2, false, 2><<<grid, 256, 0, st>>>(g);
   }
   return sgic::check_launch("gemm_f32_kernel");
 }
