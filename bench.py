@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--mode", choices=["compress", "decompress"], default="compress",
                     help="compress = the headline metric (BASELINE.json configs[1]); decompress = configs[2]/[4] secondary line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--h2d", action="store_true", help="also copy the input batch host->device inside every step "
+                    "(PCIe-inclusive rate for DESIGN.md; never the headline value)")
     ap.add_argument("--cpu-images", type=int, default=6)
     args = ap.parse_args()
 
@@ -122,9 +124,15 @@ def main():
                    zs=torch.empty(B, _sl.sgic_pack12_size(ntok), dtype=torch.uint8).pin_memory(),
                    q=torch.empty(B, clip_cfg.embed_dim, dtype=torch.uint8).pin_memory()) for _ in range(2)]
 
+    x_host = x.cpu().pin_memory() if args.h2d else None
+
     def enqueue(slot):
-        r = codec.encode_device(x, side_stream=side)
-        unit, q = clipc.batch_to_codes(x)
+        xin = x
+        if args.h2d:
+            xin = torch.empty_like(x)
+            xin.copy_(x_host, non_blocking=True)
+        r = codec.encode_device(xin, side_stream=side)
+        unit, q = clipc.batch_to_codes(xin)
         if world > 1:
             dist.all_gather_into_tensor(gathered, unit)   # CLIP vectors for the FAISS index (RCCL over xGMI)
         torch.cuda.current_stream().wait_stream(side)

@@ -83,6 +83,7 @@ struct GemmArgs {
   // m = (b,y,x) of the output, K = 9*C ordered (ky,kx,c); conv_C == 0 disables.  C % 32 == 0 so a 32-wide K
   // slice never straddles a tap (taming ResnetBlock / Upsample / conv_in / conv_out, model.py:38-137,436-537)
   int conv_C, conv_H, conv_W;
+  int stagger_cycles, per_cu;
 };
 
 __device__ __forceinline__ f32x4 ld4_guard(const float *p, bool ok) {
@@ -237,6 +238,17 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_f32_kernel(GemmAr
   };
 
   const int nk = (g.K + BK - 1) / BK;
+  // Stagger: the workgroups that land as the 2nd (3rd, 4th) resident of a CU in the first dispatch round start a
+  // fraction of a tile later, so co-resident workgroups are not in their prologue / epilogue at the same time
+  // (those phases then overlap a partner's MFMA stream instead of each other).  Placement is only assumed for
+  // speed: ids congruent mod 8 share an XCD, 32 CUs per XCD are filled in order.
+  if (g.stagger_cycles > 0) {
+    const int slot = ((int)blockIdx.x >> 3) / 32;
+    if (slot > 0 && slot < g.per_cu) {
+      const long long t_end = (long long)__builtin_amdgcn_s_memtime() + (long long)slot * g.stagger_cycles;
+      while ((long long)__builtin_amdgcn_s_memtime() < t_end) __builtin_amdgcn_s_sleep(32);
+    }
+  }
   Frag f0, f1;
   if constexpr (NBUF == 2) {
     issue_loads(0);
@@ -343,10 +355,12 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_f32_kernel(GemmAr
   }
 }
 
+static int g_stagger = 0;
 static int g_tile_override = 0;  // 0 = heuristic, 1 = 128x128, 2 = 128x64 (set by the host-side autotuner)
 extern "C" int sgic_gemm_set_tile(int mode) {
-  if (mode < 0 || mode > 4) return SGIC_EINVAL;
-  g_tile_override = mode;
+  if (mode < 0 || mode > 8) return SGIC_EINVAL;
+  g_stagger = mode > 4;                      // modes 5..8 = modes 1..4 with the start-up stagger
+  g_tile_override = mode > 4 ? mode - 4 : mode;
   return SGIC_OK;
 }
 
@@ -369,6 +383,14 @@ static int gemm_launch(GemmArgs g, int batch, hipStream_t st) {
   g.tiles_n = narrow ? (N + 63) / 64 : (N + 127) / 128;
   const bool ktail = (K % BK) != 0;
   const dim3 grid(g.tiles_m * g.tiles_n, batch);
+  {
+    const int per_cu = single ? (narrow ? 4 : 3) : 2;
+    const long total = (long)g.tiles_m * g.tiles_n * batch;
+    g.per_cu = per_cu;
+    // one tile's MFMA time alone on a CU ~ nk * 64(32 narrow) MFMAs * 64 cycles; delay resident slot s by s/per_cu of it
+    const long tile_cycles = (long)((K + BK - 1) / BK) * (narrow ? 32 : 64) * 64;
+    g.stagger_cycles = (g_stagger && total >= 2L * per_cu * 256) ? (int)(tile_cycles / per_cu) : 0;
+  }
   if (narrow) {
     if (ktail) gemm_f32_kernel<1, true, 2><<<grid, 256, 0, st>>>(g);
     else if (single) gemm_f32_kernel<1, false, 1><<<grid, 256, 0, st>>>(g);
@@ -407,7 +429,7 @@ extern "C" int sgic_gemm_f32(const float *d_A, int lda, const float *d_W, int ld
   SGIC_REQUIRE(a_seg >= 0 && c_seg >= 0 && (a_seg == 0 || a_seg_stride >= a_seg) && (c_seg == 0 || c_seg_stride >= c_seg),
                "row segment maps");
   GemmArgs g{d_A, d_W, d_bias, d_R, d_C, M, N, K, lda, ldw, ldr, ldc, act, 0, 0, a_seg, a_seg_stride, c_seg, c_seg_stride,
-             vec_ok(d_bias, d_R, ldr, d_C, ldc, N, 0, 0), 0, 0, 0, 0, 0, 0, 0};
+             vec_ok(d_bias, d_R, ldr, d_C, ldc, N, 0, 0), 0, 0, 0, 0, 0, 0, 0, 0, 0};
   return gemm_launch(g, 1, to_stream(stream));
 }
 
@@ -420,7 +442,7 @@ extern "C" int sgic_gemm_batched_f32(const float *d_A, int lda, long strideA, co
   if (rc) return rc;
   SGIC_REQUIRE(lda >= K && batch > 0 && batch < 65536 && (strideA & 3) == 0 && (strideW & 3) == 0, "batch/strides");
   GemmArgs g{d_A, d_W, d_bias, d_R, d_C, M, N, K, lda, ldw, ldr, ldc, act, 0, 0, 0, 0, 0, 0,
-             vec_ok(d_bias, d_R, ldr, d_C, ldc, N, strideC, strideR), strideA, strideW, strideC, strideR, 0, 0, 0};
+             vec_ok(d_bias, d_R, ldr, d_C, ldc, N, strideC, strideR), strideA, strideW, strideC, strideR, 0, 0, 0, 0, 0};
   return gemm_launch(g, batch, to_stream(stream));
 }
 
@@ -436,6 +458,6 @@ extern "C" int sgic_conv3x3_f32(const float *d_in_halo, const float *d_W, const 
   if (rc) return rc;
   SGIC_REQUIRE(Cin % BK == 0, "implicit-GEMM conv needs Cin % 32 == 0");
   GemmArgs g{d_in_halo, d_W, d_bias, d_R, d_out, M, Cout, K, Cin, K, ldr, ldc, act, 0, 0, 0, 0, 0, 0,
-             vec_ok(d_bias, d_R, ldr, d_out, ldc, Cout, 0, 0), 0, 0, 0, 0, Cin, H, W};
+             vec_ok(d_bias, d_R, ldr, d_out, ldc, Cout, 0, 0), 0, 0, 0, 0, Cin, H, W, 0, 0};
   return gemm_launch(g, 1, to_stream(stream));
 }
