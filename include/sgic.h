@@ -135,6 +135,9 @@ int sgic_attention_f32(const float *d_q, int ldq, const float *d_k, int ldk, con
                        float *d_out, int ldo, int L, int nseq, int nheads, const int32_t *d_rowmap,
                        const float *d_bias, const int32_t *d_biasvar, float scale, sgic_stream_t stream);
 
+/* tuning knob: maximum waves (32 query rows each) per attention workgroup, 4..10 (default 10). */
+int sgic_attention_set_max_waves(int w);
+
 /* im2col of non-overlapping PxP patches of an NCHW image with x*mul+add fused; patch rows in plain
  * (b,gy,gx) order or 16x16-tile-major (tile16) order (codec_sq_fixbpp.py:855,119; titok/blocks.py:98-100). */
 int sgic_im2col_patch(const float *d_x, int B, int C, int H, int W, int P, float mul, float add, int tile16,

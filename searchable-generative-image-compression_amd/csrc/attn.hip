@@ -196,6 +196,13 @@ __global__ __launch_bounds__(640) void attn_f32_kernel(AttnArgs a) {
   }
 }
 
+static int g_attn_max_waves = 10;
+extern "C" int sgic_attention_set_max_waves(int w) {
+  if (w < 4 || w > 10) return SGIC_EINVAL;
+  g_attn_max_waves = w;
+  return SGIC_OK;
+}
+
 extern "C" int sgic_attention_f32(const float *d_q, int ldq, const float *d_k, int ldk, const float *d_v, int ldv,
                                   float *d_out, int ldo, int L, int nseq, int nheads, const int32_t *d_rowmap,
                                   const float *d_bias, const int32_t *d_biasvar, float scale, sgic_stream_t stream) {
@@ -205,7 +212,8 @@ extern "C" int sgic_attention_f32(const float *d_q, int ldq, const float *d_k, i
   SGIC_REQUIRE((((uintptr_t)d_q | (uintptr_t)d_k | (uintptr_t)d_v | (uintptr_t)d_out) & 15) == 0, "16-byte alignment");
   SGIC_REQUIRE(!d_bias || (L & 3) == 0, "bias needs L % 4 == 0");
   const int rows32 = (L + 31) / 32;             // 32-row wave slices needed
-  const int qblocks = (rows32 + 9) / 10;        // at most 10 waves (640 threads) per workgroup
+  const int mw = g_attn_max_waves;
+  const int qblocks = (rows32 + mw - 1) / mw;   // at most 10 waves (640 threads) per workgroup
   int nwaves = (rows32 + qblocks - 1) / qblocks;
   if (nwaves < 4) nwaves = 4;                   // >= 256 threads so the 2-slot K/V staging covers a tile
   AttnArgs a{d_q, d_k, d_v, d_out, ldq, ldk, ldv, ldo, L, nseq, nheads, d_rowmap, d_bias, d_biasvar, scale, nwaves, qblocks};

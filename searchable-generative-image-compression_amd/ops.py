@@ -139,8 +139,35 @@ def attention(q, k, v, out, L, nseq, nheads, rowmap=None, bias=None, biasvar=Non
         assert bias.dim() == 3 and bias.shape[1] == L and bias.shape[2] == L and bias.is_contiguous()
     if biasvar is not None:
         assert biasvar.dtype == torch.int32 and biasvar.numel() == nseq
-    call("sgic_attention_f32", _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), ldo, L, nseq, nheads, _p(rowmap), _p(bias),
-         _p(biasvar), float(scale))
+    def launch():
+        call("sgic_attention_f32", _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), ldo, L, nseq, nheads, _p(rowmap), _p(bias),
+             _p(biasvar), float(scale))
+
+    # waves per workgroup (4 / 8 / 10 x 32 query rows): padding waste vs SIMD balance vs workgroups per CU depends on
+    # L (measured: L=256 and 545 want 4, L=289 wants 10) -> tuned per shape like the GEMM tiles; results are identical.
+    from ._lib import lib
+    mw = 10
+    if AUTOTUNE:
+        key = ("attn", L, nseq, nheads, bias is not None, str(q.device))
+        mw = _TILE.get(key)
+        if mw is None:
+            best_t = None
+            for cand in (4, 8, 10):
+                lib.sgic_attention_set_max_waves(cand)
+                launch()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    launch()
+                e1.record()
+                e1.synchronize()
+                t = e0.elapsed_time(e1)
+                if best_t is None or t < best_t:
+                    mw, best_t = cand, t
+            _TILE[key] = mw
+    if AUTOTUNE:
+        lib.sgic_attention_set_max_waves(mw)
+    launch()
     return out
 
 
@@ -289,7 +316,21 @@ def conv3x3(x_halo, w, bias, B, H, W, Cin, Cout, residual=None, act=ACT_NONE, ou
     ldr = 0
     if residual is not None:
         residual, ldr = _rows(residual)
-    call("sgic_conv3x3_f32", _p(x_halo), _p(w), _p(bias), _p(residual), ldr, _p(out), ldc, B, H, W, Cin, Cout, act)
+    def launch():
+        call("sgic_conv3x3_f32", _p(x_halo), _p(w), _p(bias), _p(residual), ldr, _p(out), ldc, B, H, W, Cin, Cout, act)
+
+    tile = 0
+    if AUTOTUNE and B * H * W * Cout >= (1 << 20):
+        key = ("conv3x3", B, H, W, Cin, Cout, residual is not None, act, str(x_halo.device))
+        tile = _TILE.get(key)
+        if tile is None:
+            tile = _tune(key, launch)     # conv outputs never alias their residual: re-running is idempotent
+    if tile:
+        from ._lib import lib
+        lib.sgic_gemm_set_tile(tile)
+    launch()
+    if tile:
+        lib.sgic_gemm_set_tile(0)
     return out
 
 

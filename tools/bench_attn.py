@@ -1,0 +1,29 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import sgic_amd
+from sgic_amd import ops
+from sgic_amd._lib import lib
+dev = torch.device("cuda:0")
+ops.AUTOTUNE = False
+torch.manual_seed(0)
+for (L, nseq, heads, bias) in [(289, 32, 16, False), (545, 32, 12, False), (256, 32, 12, True), (50, 32, 12, False)]:
+    D = heads * 64
+    qkv = torch.randn(nseq * L, 3 * D, device=dev)
+    out = torch.empty(nseq * L, D, device=dev)
+    b = torch.randn(1, L, L, device=dev) if bias else None
+    fl = 4.0 * L * L * 64 * heads * nseq
+    res = []
+    for mw in (4, 5, 6, 8, 9, 10):
+        lib.sgic_attention_set_max_waves(mw)
+        for _ in range(3):
+            ops.attention(qkv[:, :D], qkv[:, D:2*D], qkv[:, 2*D:], out, L, nseq, heads, bias=b)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ops.attention(qkv[:, :D], qkv[:, D:2*D], qkv[:, 2*D:], out, L, nseq, heads, bias=b)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        res.append(f"mw{mw}: {ms*1e3:6.1f}us {fl/ms/1e9:5.1f}TF")
+    print(f"L={L} heads={heads}: " + "  ".join(res), flush=True)
