@@ -158,11 +158,11 @@ __global__ __launch_bounds__(640) void attn_f32_kernel(AttnArgs a) {
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx);
     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // whole row masked so far
-    const float alpha = expf(m_run - m_use);                 // m_run = -inf -> 0
+    const float alpha = __expf(m_run - m_use);               // m_run = -inf -> 0 (v_exp_f32 path: ~3e-6 rel. at |x| = 50)
     float psum = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; e++) {
-      s[e] = expf(s[e] - m_use);
+      s[e] = __expf(s[e] - m_use);
       psum += s[e];
     }
     l_run = l_run * alpha + psum;
