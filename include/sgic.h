@@ -85,6 +85,8 @@ int sgic_unpack12_batch(const uint8_t *d_in, int B, int n, int32_t *d_idx, sgic_
 int sgic_quant_step(const float *d_y, const float *d_scales, const float *d_means, int ld_sm, float *d_yhat,
                     int ld_yhat, int B, int H, int W, int C, int k, float thr, int16_t *d_sym, int16_t *d_idx,
                     sgic_stream_t stream);
+/* GaussianEncoder.build_indexes on a flat array (entropy/entropy_models.py:355-362); thr < 0: no skip marking. */
+int sgic_scale_to_index(const float *d_scales, long n, float thr, int16_t *d_idx, sgic_stream_t stream);
 /* Decoder twins (compression_model.py:377-418): indexes from scales for step k, and
  * y_hat[active] = sym + mean after the symbols were decoded. */
 int sgic_index_step(const float *d_scales, int ld_sm, int B, int H, int W, int C, int k, float thr,

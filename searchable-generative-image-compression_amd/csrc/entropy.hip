@@ -478,6 +478,19 @@ __global__ void quant_step_kernel(const float *__restrict__ y, const float *__re
   }
 }
 
+// flat GaussianEncoder.build_indexes (entropy_models.py:355-362): idx = trunc(clamp((ln max(s,1e-5) - ln .11)/step, 0, 255)),
+// -1 where max(s,1e-5) < thr
+__global__ void scale_to_index_kernel(const float *__restrict__ scales, long n, float thr, int16_t *__restrict__ idx) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    idx[i] = (int16_t)scale_to_index(scales[i], thr);
+}
+
+extern "C" int sgic_scale_to_index(const float *d_scales, long n, float thr, int16_t *d_idx, sgic_stream_t stream) {
+  SGIC_REQUIRE(d_scales && d_idx && n > 0, "args");
+  scale_to_index_kernel<<<cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256), 256, 0, to_stream(stream)>>>(d_scales, n, thr, d_idx);
+  return sgic::check_launch("scale_to_index_kernel");
+}
+
 extern "C" int sgic_quant_step(const float *d_y, const float *d_scales, const float *d_means, int ld_sm,
                                float *d_yhat, int ld_yhat, int B, int H, int W, int C, int k, float thr,
                                int16_t *d_sym, int16_t *d_idx, sgic_stream_t stream) {

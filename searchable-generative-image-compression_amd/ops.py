@@ -271,6 +271,10 @@ def quant_step(y, scales, means, ld_sm, yhat, ld_yhat, B, H, W, C, k, thr, sym, 
          float(-1.0 if thr is None else thr), _p(sym), _p(idx))
 
 
+def scale_indexes(scales_flat, idx_out, thr):
+    call("sgic_scale_to_index", _p(scales_flat), _cl(scales_flat.numel()), float(-1.0 if thr is None else thr), _p(idx_out))
+
+
 def index_step(scales, ld_sm, B, H, W, C, k, thr, idx):
     call("sgic_index_step", _p(scales), ld_sm, B, H, W, C, k, float(-1.0 if thr is None else thr), _p(idx))
 

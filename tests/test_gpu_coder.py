@@ -169,3 +169,60 @@ def test_quant_step_vs_oracle_bit_exact():
                 assert np.array_equal(h_sym[b, k], s), (B, H, W, b, k)
                 assert np.array_equal(h_idx[b, k], i), (B, H, W, b, k)
             assert np.array_equal(h_yhat[b], ref_hat)
+
+
+def test_reference_named_entropy_api(tab):
+    """the L3 mirrors (entropy.entropy_models.EntropyCoder / GaussianEncoder) behave like the reference's:
+    encode(x, scales, thr) x4 -> flush -> bytes == C oracle; decode_stream continues the cursor"""
+    import sgic_amd  # noqa
+    from sgic_amd.entropy.entropy_models import EntropyCoder, GaussianEncoder
+    ec = EntropyCoder(False, 1)
+    ge = GaussianEncoder("gaussian")
+    ge.update(force=True, entropy_coder=ec)
+    rng = np.random.default_rng(4)
+    scales = [torch.from_numpy(np.exp(rng.uniform(np.log(0.05), np.log(40), size=(1, 16, 8, 8))).astype(np.float32)).cuda() for _ in range(4)]
+    xs = [torch.from_numpy(np.rint(rng.standard_normal((1, 16, 8, 8)) * 3).astype(np.float32)).cuda() for _ in range(4)]
+    ec.reset()
+    for x, s in zip(xs, scales):
+        ge.encode(x, s, skip_thres=0.12)
+    ec.flush()
+    stream = ec.get_encoded_stream()
+    # oracle: same index formula in numpy float32 + C coder
+    log_min, log_step = np.float32(np.log(0.11)), np.float32((np.log(64.0) - np.log(0.11)) / 255)
+    syms, idxs = [], []
+    for x, s in zip(xs, scales):
+        sc = np.maximum(s.cpu().numpy().reshape(-1), np.float32(1e-5))
+        fi = np.clip((np.log(sc.astype(np.float64)).astype(np.float32) - log_min) / log_step, 0, 255).astype(np.int32)
+        fi[sc < np.float32(0.12)] = -1
+        idxs.append(fi.astype(np.int16))
+        syms.append(x.cpu().numpy().reshape(-1).astype(np.int16))
+    assert stream == orc.rans_encode(np.concatenate(syms), np.concatenate(idxs), orc.Table(*tab))
+    ec.set_stream(stream)
+    for x, s, i in zip(xs, scales, idxs):
+        got = ge.decode_stream(s, torch.float32, "cpu", skip_thres=0.12)
+        assert np.array_equal(got.numpy().reshape(-1), np.where(i < 0, 0, x.cpu().numpy().reshape(-1)))
+
+
+def test_reference_named_codec_plugin():
+    """`target: models.codec_sq_fixbpp.Codec` constructed from the reference's YAML kwargs (config_test.yaml)"""
+    import sgic_amd  # noqa
+    from sgic_amd.config import SMALL
+    from sgic_amd.data import synth_images
+    from sgic_amd.entropy.compression_model import get_padding_size
+    from sgic_amd.models.codec_sq_fixbpp import Codec
+    params = dict(embed_dim=64, feat_dim=256, in_pos_enc=[1, 5], in_pos_dec=[1, 5], n_attn=2, config=SMALL.titok_dict(),
+                  vqganconfig=dict(embed_dim=64, n_embed=64, ddconfig=SMALL.vqgan_ddconfig(), lossconfig=None),
+                  imglossconfig={}, featlossconfig={}, training_strategy={"learning_rate": 5e-5}, monitor="saved_loss",
+                  ckpt_path=None, ignore_keys=['epoch_for_strategy', 'lmbda_idx', 'lmbda_list'], titok_pretrain_path=None,
+                  tune_titok=False, no_attn_vqgan=False)
+    model = Codec(**params).to("cuda:0").eval()
+    model.hybrid_codec.quantize_feat.force_zero_thres = 0.12
+    model.hybrid_codec.quantize_feat.update(force=True)
+    assert model.cfg == SMALL
+    img = synth_images(1, 256, 256, 7)[:, :, :200, :231]
+    pl, pr, pt, pb = get_padding_size(200, 231, p=256)
+    xp = torch.nn.functional.pad(img, (pl, pr, pt, pb), mode="replicate")
+    enc = model.encode_only(xp.cuda())
+    assert set(enc) == {"z_bit_stream", "h_bit_stream", "img_shape", "feat_shape", "stack_shape", "token_length", "z_indices_shape"}
+    x_hat = model.decode_only(**enc, clip_stream=b"", clip_meta={})
+    assert x_hat.shape == (1, 3, 256, 256)
