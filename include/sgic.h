@@ -117,7 +117,8 @@ int sgic_gemm_f32(const float *d_A, int lda, const float *d_W, int ldw, const fl
 /* Tile override for the following GEMM / conv launches of this process: 0 = built-in heuristic, 1 = 128x128,
  * 2 = 128x64 workgroup tiles (double-buffered LDS), 3 / 4 = the same tiles with a single LDS buffer (3-4 workgroups per CU),
  * 5..8 = 1..4 with a start-up stagger of the co-resident workgroups (their prologue/epilogue phases then overlap a
- * partner's MFMA stream instead of each other).  Results are bitwise identical for every choice (the k order is fixed); the host
+ * partner's MFMA stream instead of each other), 9 / 10 = MIXED: whole rounds of 128x128 tiles for the bulk of the
+ * rows + 64x64 tiles for the remaining rows in the same launch (2 / 1 LDS buffers).  Results are bitwise identical for every choice (the k order is fixed); the host
  * autotuner (sgic_amd.ops) uses it to pick the faster tile per GEMM shape. */
 int sgic_gemm_set_tile(int mode);
 

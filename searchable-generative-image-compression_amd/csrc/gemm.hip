@@ -1,22 +1,30 @@
 // fp32 GEMM on the CDNA4 matrix cores:  C[M,N] = epilogue( A[M,K] . W[N,K]^T )
 //
-// This is THE dominant kernel of the codec (>= 97 % of the FLOPs: every nn.Linear, 1x1 conv, the
-// patch-embed / 2x2 convs as im2col GEMMs; reference call sites titok/blocks.py:37-64,
+// This is THE dominant kernel of the codec (>= 95 % of the FLOPs: every nn.Linear, 1x1 conv, the patch-embed /
+// 2x2 convs as im2col GEMMs, the VQGAN 3x3 convs as implicit GEMMs; reference call sites titok/blocks.py:37-64,
 // blocks/swin_transformer.py:94-156, models/cross_blocks.py:75-98, blocks/conv_blocks.py:71-81,
-// blocks/dcvc.py:28-54).  The reference computes in fp32, so we use the exact-fp32 MFMA
-// v_mfma_f32_32x32x2_f32 (64 FLOP/clk/SIMD, 157 TFLOP/s chip peak); its result is bit-for-bit a
-// k-ordered fmaf chain, and the k order here is fixed by K alone (no split-K), so every output row is
-// independent of M and of the batch it sits in (batch-invariant: B=32 equals 32 x B=1).
+// blocks/dcvc.py:28-54, taming/modules/diffusionmodules/model.py:38-192).  The reference computes in fp32, so
+// we use the exact-fp32 MFMA v_mfma_f32_32x32x2_f32 (64 FLOP/clk/SIMD, 157.3 TFLOP/s chip peak); its result is
+// bit-for-bit a k-ordered fmaf chain, and the k order here is fixed by K alone (no split-K / stream-K), so every
+// output row is independent of M, of the tile shape and of the batch it sits in (batch-invariant).
 //
-// Tiling (wave64): 256 threads = 4 waves as 2(M) x 2(N); workgroup tile 128x128, wave tile 64x64 =
-// 2x2 MFMA 32x32 blocks (64 accumulator VGPRs); BK = 32.  A and W tiles are staged global -> VGPR
-// (float4, issued before the MFMA phase so HBM/L2 latency hides under 64 MFMAs per wave) -> LDS with
-// a 36-float row stride (144 B: the 16 lanes of a ds_read_b128 group hit 16 distinct 16-B slots).
-// Each lane fetches its operands with ds_read_b128 (4 consecutive k of one row); MFMA step t of a
-// group uses element t of both fragments, i.e. lanes 0-31 feed k = 8s+t and lanes 32-63 k = 8s+4+t.
-// 36 KB LDS and ~110 VGPRs per workgroup -> 2-3 workgroups per CU, so one workgroup's staging
-// overlaps another's MFMAs.  blockIdx is remapped (bijectively) so that the workgroups sharing an
-// XCD's L2 work on neighbouring tiles of the same A row-panels.
+// Tiling (wave64): 256 threads = 4 waves as 2(M) x 2(N); wave tile (32*WM) x (32*WN) MFMA blocks, workgroup tile
+// (64*WM) x (64*WN): 128x128 (2,2), 128x64 (2,1), 64x64 (1,1); BK = 32.
+//  * staging: A/W tiles global -> VGPR (float4, UNCONDITIONAL loads; out-of-range rows are clamped -- they only
+//    feed accumulator rows/columns the epilogue never stores) -> LDS with a 36-float row stride (the 16 lanes of a
+//    ds_read_b128 group hit 16 distinct 16-byte slots: conflict-free);
+//  * pipeline (NBUF = 2): double-buffered LDS, ONE barrier per K-step; tile k+2's loads are issued at the top of
+//    step k and first touched by the ds_write one step later; MFMA fragments are double-buffered in registers and
+//    the barrier sits before the last sub-step, after which the next tile's first fragments are prefetched.
+//    NBUF = 1: one LDS buffer, two barriers per step, but 3-4 workgroups per CU;
+//  * operands: ds_read_b128 (4 consecutive k per lane); MFMA step t uses element t of both fragments, i.e.
+//    lanes 0-31 feed k = 8s+t and lanes 32-63 k = 8s+4+t (a fixed permutation of the k order);
+//  * epilogue: per-wave LDS transpose, whole 128/256-byte row segments stored as dwordx4 with bias ->
+//    activation -> residual fused;
+//  * order: XCD-aware bijective block remap + grouped (8 m-tiles x all n-tiles) walk for L2 reuse;
+//  * MIXED launch: the bulk of the rows uses 128x128 tiles in whole rounds of the 256 CUs, the remaining rows use
+//    64x64 tiles inside the SAME launch, so the last round of workgroups is short instead of leaving most CUs idle
+//    (M = 9248 = 72.25 tiles is never a multiple of the machine).
 #include <math.h>
 
 #include "common.h"
@@ -24,15 +32,13 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define BM 128
-#define BN 128
 #define BK 32
 #define LDS_LD 36
 
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_TANH = 3, ACT_LRELU = 4 };
 
 // erf(x) for the exact-GELU epilogue: clamp to [-4,4] and evaluate a (6,4) rational minimax in x^2 -- the
-// float32 erf approximant used by Eigen / XLA (max abs error a few 1e-7, i.e. fp32 rounding level), branch-free
+// float32 erf approximant used by Eigen / XLA (max abs error 4e-7, i.e. fp32 rounding level), branch-free
 // and ~3x cheaper than the libm erff, which matters because every workgroup finishes at the same time.
 __device__ __forceinline__ float fast_erf(float x) {
   x = fminf(fmaxf(x, -4.f), 4.f);
@@ -72,7 +78,6 @@ struct GemmArgs {
   int M, N, K;
   int lda, ldw, ldr, ldc;
   int act;
-  int tiles_m, tiles_n;
   // optional row maps  row(m) = (m / seg) * seg_stride + (m % seg)  (seg == 0: identity) so a GEMM can
   // read / write the [:, a:b] token slice of an (n, L, C) buffer in place (models/cross_blocks.py:87-94)
   int a_seg, a_seg_stride, c_seg, c_seg_stride;
@@ -84,74 +89,43 @@ struct GemmArgs {
   // slice never straddles a tap (taming ResnetBlock / Upsample / conv_in / conv_out, model.py:38-137,436-537)
   int conv_C, conv_H, conv_W;
   int stagger_cycles, per_cu;
+  // tile regions: rows [0, m_split) are covered by `big_blocks` workgroups of the kernel's primary tile, rows
+  // [m_split, M) by 64x64 tiles (MIXED kernels only; otherwise m_split == M)
+  int m_split, big_blocks;
 };
 
-__device__ __forceinline__ f32x4 ld4_guard(const float *p, bool ok) {
-  f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  return ok ? *reinterpret_cast<const f32x4 *>(p) : z;
-}
+// One output tile.  bid = workgroup index inside its region, rows [row_base, row_end) x all N.
+template <int WM, int WN, bool KTAIL, int NBUF>
+__device__ __forceinline__ void gemm_tile(const GemmArgs &g, int bid, int row_base, int row_end, float *smem) {
+  constexpr int TBM = 64 * WM, TBN = 64 * WN;       // workgroup tile
+  constexpr int NA4 = TBM / 32, NB4 = TBN / 32;     // float4 staged per thread (rows x 8 chunks / 256 threads)
+  float(*sA)[TBM * LDS_LD] = reinterpret_cast<float(*)[TBM * LDS_LD]>(smem);
+  float(*sB)[TBN * LDS_LD] = reinterpret_cast<float(*)[TBN * LDS_LD]>(smem + NBUF * TBM * LDS_LD);
 
-// WN = MFMA column blocks per wave: 2 -> workgroup tile 128x128, 1 -> 128x64 (finer tiles for GEMMs whose
-// 128x128 grid would leave CUs idle in the last wave of workgroups).
-//
-// Pipeline (one barrier per K-step, MFMA stream never waits on LDS or HBM in steady state):
-//   top of step kt : ds_write tile kt+1 (VGPR staging, loaded one step ago) into the OTHER LDS buffer,
-//                    issue the global loads of tile kt+2
-//   sub-steps 0..2 : MFMAs on the current buffer, fragments of sub-step s+1 prefetched (2 register sets)
-//   barrier        : tile kt+1 visible, nobody reads the current buffer any more
-//   sub-step 3     : prefetch sub-step 0 of tile kt+1 from the other buffer, then the last 16/8 MFMAs
-template <int WN, bool KTAIL, int NBUF>
-__global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_f32_kernel(GemmArgs g) {
-  constexpr int TBN = 64 * WN;          // workgroup tile N
-  constexpr int NB4 = TBN / 32;         // float4 staged per thread for the W tile (TBN rows x 8 chunks / 256)
-  // one LDS array: [A buf0 | A buf1 | W buf0 | W buf1]; the epilogue reuses it as 4 per-wave transpose tiles
-  // NBUF = 2: double-buffered LDS, one barrier per K-step, 2 workgroups per CU.  NBUF = 1: single buffer, two
-  // barriers per K-step but 3 workgroups per CU (more waves to cover each other's barrier / epilogue phases).
-  constexpr int EP_FLOATS = 4 * 32 * 32 * WN;  // epilogue transpose slices of the 4 waves (32 rows at a time)
-  constexpr int ST_FLOATS = NBUF * (BM + TBN) * LDS_LD;
-  __shared__ __attribute__((aligned(16))) float smem[ST_FLOATS > EP_FLOATS ? ST_FLOATS : EP_FLOATS];
-  float(*sA)[BM * LDS_LD] = reinterpret_cast<float(*)[BM * LDS_LD]>(smem);
-  float(*sB)[TBN * LDS_LD] = reinterpret_cast<float(*)[TBN * LDS_LD]>(smem + NBUF * BM * LDS_LD);
-
-  // ---- XCD-aware bijective remap: hardware deals consecutive block ids round-robin over 8 XCDs ----
-  const int nwg = g.tiles_m * g.tiles_n;
-  int bid = blockIdx.x;
+  // ---- tile order: XCD-aware bijective remap (consecutive workgroup ids are dealt round-robin over the 8 XCDs,
+  // ids congruent mod 8 share an L2), then a grouped walk (8 m-tiles x all n-tiles, m fastest) so the ~64
+  // workgroups resident on one XCD cover an ~8x8 patch of tiles and reuse each other's A / W k-slices in L2.
+  const int tiles_m = (row_end - row_base + TBM - 1) / TBM, tiles_n = (g.N + TBN - 1) / TBN;
+  const int nwg = tiles_m * tiles_n;
   {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, within = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
   }
-  // grouped order inside the XCD's chunk: 8 consecutive m-tiles x all n-tiles form a group that is walked
-  // m-fastest, so the ~64 workgroups resident on one XCD cover an ~8x8 patch of tiles: every A / W k-slice
-  // fetched into that XCD's L2 is reused by ~8 workgroups (instead of 2..3 with plain row-major order)
   constexpr int GROUP_M = 8;
-  const int per_group = GROUP_M * g.tiles_n;
+  const int per_group = GROUP_M * tiles_n;
   const int group = bid / per_group, first_m = group * GROUP_M;
-  const int gsz = min(g.tiles_m - first_m, GROUP_M);
+  const int gsz = min(tiles_m - first_m, GROUP_M);
   const int in_group = bid - group * per_group;
-  const int tm = first_m + in_group % gsz, tn = in_group / gsz;
-  const int m0 = tm * BM, n0 = tn * TBN;
-  {
-    const long bz = blockIdx.y;
-    g.A += bz * g.sA;
-    g.W += bz * g.sW;
-    g.C += bz * g.sC;
-    if (g.R) g.R += bz * g.sR;
-  }
+  const int m0 = row_base + (first_m + in_group % gsz) * TBM, n0 = (in_group / gsz) * TBN;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * (32 * WN);
-
-  // staging map: rows (tid>>3) + 32*i, 16-byte chunk (tid&7) of the 32-float K slice
-  const int srow = tid >> 3, schunk = tid & 7;
-  f32x4 ra[4], rb[NB4];
-  const float *aptr[4];
+  const int wm = (wave >> 1) * (32 * WM), wn = (wave & 1) * (32 * WN);
+  const int srow = tid >> 3, schunk = tid & 7;  // staging map: rows srow + 32*i, 16-byte chunk schunk of the K slice
+  f32x4 ra[NA4], rb[NB4];
+  const float *aptr[NA4];
   const float *wptr[NB4];
-  // Staging loads are UNCONDITIONAL (a guarded load compiles to a branch + drained wait per load):
-  // out-of-range rows are clamped to the last valid row -- they only feed accumulator rows/columns that the
-  // epilogue never stores -- and the K tail (only when K % 32 != 0) is clamped in address and zeroed by a
-  // select on the loaded value.
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < NA4; i++) {
     const int am = min(m0 + srow + 32 * i, g.M - 1);
     size_t arow;
     if (g.conv_C) {  // top-left pixel of the 3x3 patch in the halo buffer
@@ -168,10 +142,9 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_f32_kernel(GemmAr
     wptr[i] = g.W + (size_t)wr * g.ldw;
   }
 
-  // KTAIL = false (K % 32 == 0, every large GEMM of the model): plain loads whose results are first touched
-  // by the ds_write one K-step later, so their latency hides under a full MFMA phase.  KTAIL = true: the
-  // tail chunk is clamped in address and zeroed by a select (this consumes the load early -- slow path, only
-  // used for odd K such as the 12-wide decoder embedding).
+  // KTAIL = false (K % 32 == 0, every large GEMM of the model): plain loads whose results are first touched by
+  // the ds_write one K-step later, so their latency hides under a full MFMA phase.  KTAIL = true: the tail chunk
+  // is clamped in address and zeroed by a select (this consumes the load early -- slow path, odd K only).
   auto issue_loads = [&](int k0) {
     if constexpr (!KTAIL) {
       int ka = k0;
@@ -180,7 +153,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_f32_kernel(GemmAr
         ka = (ky * (g.conv_W + 2) + kx) * g.conv_C + c0;
       }
 #pragma unroll
-      for (int i = 0; i < 4; i++) ra[i] = *reinterpret_cast<const f32x4 *>(aptr[i] + ka + schunk * 4);
+      for (int i = 0; i < NA4; i++) ra[i] = *reinterpret_cast<const f32x4 *>(aptr[i] + ka + schunk * 4);
 #pragma unroll
       for (int i = 0; i < NB4; i++) rb[i] = *reinterpret_cast<const f32x4 *>(wptr[i] + k0 + schunk * 4);
     } else {
@@ -189,7 +162,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_f32_kernel(GemmAr
       const int kc = kok ? kk : g.K - 4;
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
+      for (int i = 0; i < NA4; i++) {
         const f32x4 v = *reinterpret_cast<const f32x4 *>(aptr[i] + kc);
         ra[i] = kok ? v : z;
       }
@@ -202,14 +175,14 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_f32_kernel(GemmAr
   };
   auto store_lds = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) *reinterpret_cast<f32x4 *>(&sA[buf][(srow + 32 * i) * LDS_LD + schunk * 4]) = ra[i];
+    for (int i = 0; i < NA4; i++) *reinterpret_cast<f32x4 *>(&sA[buf][(srow + 32 * i) * LDS_LD + schunk * 4]) = ra[i];
 #pragma unroll
     for (int i = 0; i < NB4; i++) *reinterpret_cast<f32x4 *>(&sB[buf][(srow + 32 * i) * LDS_LD + schunk * 4]) = rb[i];
   };
 
-  f32x16 acc[2][WN];
+  f32x16 acc[WM][WN];
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < WM; i++)
 #pragma unroll
     for (int j = 0; j < WN; j++)
 #pragma unroll
@@ -218,13 +191,12 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_f32_kernel(GemmAr
   const int lrow = lane & 31, lhalf = lane >> 5;
   const int aoff = (wm + lrow) * LDS_LD + lhalf * 4;
   const int boff = (wn + lrow) * LDS_LD + lhalf * 4;
-
   struct Frag {
-    f32x4 a[2], b[WN];
+    f32x4 a[WM], b[WN];
   };
   auto read_frag = [&](Frag &f, int buf, int s) {
 #pragma unroll
-    for (int i = 0; i < 2; i++) f.a[i] = *reinterpret_cast<const f32x4 *>(&sA[buf][aoff + i * 32 * LDS_LD + s * 8]);
+    for (int i = 0; i < WM; i++) f.a[i] = *reinterpret_cast<const f32x4 *>(&sA[buf][aoff + i * 32 * LDS_LD + s * 8]);
 #pragma unroll
     for (int j = 0; j < WN; j++) f.b[j] = *reinterpret_cast<const f32x4 *>(&sB[buf][boff + j * 32 * LDS_LD + s * 8]);
   };
@@ -232,16 +204,15 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_f32_kernel(GemmAr
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int i = 0; i < 2; i++)
+      for (int i = 0; i < WM; i++)
 #pragma unroll
         for (int j = 0; j < WN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][t], f.b[j][t], acc[i][j], 0, 0, 0);
   };
 
   const int nk = (g.K + BK - 1) / BK;
-  // Stagger: the workgroups that land as the 2nd (3rd, 4th) resident of a CU in the first dispatch round start a
-  // fraction of a tile later, so co-resident workgroups are not in their prologue / epilogue at the same time
-  // (those phases then overlap a partner's MFMA stream instead of each other).  Placement is only assumed for
-  // speed: ids congruent mod 8 share an XCD, 32 CUs per XCD are filled in order.
+  // Stagger (optional): the workgroups that land as the 2nd (3rd, 4th) resident of a CU in the first dispatch
+  // round start a fraction of a tile later, so co-resident workgroups are not in their prologue / epilogue at the
+  // same time.  Placement is only assumed for speed: ids congruent mod 8 share an XCD, 32 CUs per XCD fill in order.
   if (g.stagger_cycles > 0) {
     const int slot = ((int)blockIdx.x >> 3) / 32;
     if (slot > 0 && slot < g.per_cu) {
@@ -297,19 +268,19 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_f32_kernel(GemmAr
 
   // ---- epilogue.  Accumulator layout: D[row = (e&3) + 8*(e>>2) + 4*lhalf][col = lrow] ----
   if (g.vec_epilogue) {
-    // Wide stores: each wave transposes its 64 x (32*WN) tile through its private slice of LDS (nobody reads
-    // the staging buffers after the last barrier) and writes whole 128/256-byte row segments as dwordx4 --
+    // Wide stores: each wave transposes its accumulators 32 rows at a time through its private LDS slice (nobody
+    // reads the staging buffers after the last barrier) and writes whole 128/256-byte row segments as dwordx4 --
     // 4x fewer store instructions than one dword per lane, which is what bounds a lock-stepped epilogue.
     constexpr int TW = 32 * WN;            // wave tile width (floats)
     constexpr int LPR = TW / 4;            // lanes per row (float4 each)
     constexpr int RPI = 64 / LPR;          // rows per store instruction
-    float *ep = smem + wave * (32 * TW);   // 32 x TW floats per wave, used twice (upper / lower 32 rows)
+    float *ep = smem + wave * (32 * TW);
     const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
     const int n = n0 + wn + c4;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (g.bias && n < g.N) bv = *reinterpret_cast<const f32x4 *>(g.bias + n);
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < WM; i++) {
 #pragma unroll
       for (int j = 0; j < WN; j++)
 #pragma unroll
@@ -320,7 +291,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_f32_kernel(GemmAr
         for (int it = 0; it < 32 / RPI; ++it) {
           const int r = it * RPI + r0;
           const int m = m0 + wm + i * 32 + r;
-          if (m < g.M) {
+          if (m < row_end) {
             f32x4 v = *reinterpret_cast<const f32x4 *>(ep + r * TW + c4);
 #pragma unroll
             for (int t = 0; t < 4; t++) v[t] = apply_act(v[t] + bv[t], g.act);
@@ -340,11 +311,11 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_f32_kernel(GemmAr
     if (n >= g.N) continue;
     const float bv = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < WM; i++) {
 #pragma unroll
       for (int e = 0; e < 16; e++) {
         const int m = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
-        if (m < g.M) {
+        if (m < row_end) {
           float v = apply_act(acc[i][j][e] + bv, g.act);
           if (g.R) v += g.R[(size_t)m * g.ldr + n];
           const size_t crow = g.c_seg ? (size_t)(m / g.c_seg) * g.c_seg_stride + (m % g.c_seg) : (size_t)m;
@@ -355,12 +326,38 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_f32_kernel(GemmAr
   }
 }
 
+// MIXED: workgroups >= g.big_blocks compute 64x64 tiles of the rows [m_split, M) (same launch, same pipeline)
+template <int WM, int WN, bool KTAIL, int NBUF, bool MIXED>
+__global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_f32_kernel(GemmArgs g) {
+  constexpr int TBM = 64 * WM, TBN = 64 * WN;
+  constexpr int EP_FLOATS = 4 * 32 * 32 * WN;  // epilogue transpose slices of the 4 waves (32 rows at a time)
+  constexpr int ST_FLOATS = NBUF * (TBM + TBN) * LDS_LD;
+  // one LDS array: [A buffers | W buffers]; the epilogue reuses it as 4 per-wave transpose slices
+  __shared__ __attribute__((aligned(16))) float smem[ST_FLOATS > EP_FLOATS ? ST_FLOATS : EP_FLOATS];
+  {
+    const long bz = blockIdx.y;
+    g.A += bz * g.sA;
+    g.W += bz * g.sW;
+    g.C += bz * g.sC;
+    if (g.R) g.R += bz * g.sR;
+  }
+  if constexpr (MIXED) {
+    if ((int)blockIdx.x >= g.big_blocks) {
+      gemm_tile<1, 1, KTAIL, NBUF>(g, (int)blockIdx.x - g.big_blocks, g.m_split, g.M, smem);
+      return;
+    }
+  }
+  gemm_tile<WM, WN, KTAIL, NBUF>(g, (int)blockIdx.x, 0, g.m_split, smem);
+}
+
 static int g_stagger = 0;
-static int g_tile_override = 0;  // 0 = heuristic, 1 = 128x128, 2 = 128x64 (set by the host-side autotuner)
+static int g_tile_override = 0;
+// 0 = heuristic; 1 = 128x128 / 2 LDS buffers, 2 = 128x64 / 2 buffers, 3 = 128x128 / 1 buffer, 4 = 128x64 / 1 buffer,
+// 5..8 = 1..4 with the start-up stagger, 9 = mixed 128x128 + 64x64 tail (2 buffers), 10 = mixed, 1 buffer
 extern "C" int sgic_gemm_set_tile(int mode) {
-  if (mode < 0 || mode > 8) return SGIC_EINVAL;
-  g_stagger = mode > 4;                      // modes 5..8 = modes 1..4 with the start-up stagger
-  g_tile_override = mode > 4 ? mode - 4 : mode;
+  if (mode < 0 || mode > 10) return SGIC_EINVAL;
+  g_stagger = (mode >= 5 && mode <= 8);
+  g_tile_override = g_stagger ? mode - 4 : mode;
   return SGIC_OK;
 }
 
@@ -368,37 +365,59 @@ static int gemm_launch(GemmArgs g, int batch, hipStream_t st) {
   const int M = g.M, N = g.N, K = g.K;
   // Tile choice: 128x128 unless the 128x64 grid fills the last round of workgroups on the 256 CUs clearly
   // better (workgroups are dispatched dynamically, so the makespan is ~ceil(blocks / 256) block-times).
-  const int tm = (M + BM - 1) / BM;
+  const int tm128 = (M + 127) / 128;
   auto eff = [&](int bn) {
-    const double nb = (double)tm * ((N + bn - 1) / bn) * batch / 256.0;
+    const double nb = (double)tm128 * ((N + bn - 1) / bn) * batch / 256.0;
     return nb / ceil(nb);
   };
   bool narrow = N <= 64 || eff(64) > eff(128) + 0.04;
-  bool single = false;  // tile modes: 1 = 128x128 / 2 buffers, 2 = 128x64 / 2 buffers, 3 = 128x128 / 1 buffer, 4 = 128x64 / 1 buffer
+  bool single = false, mixed = false;
   if (g_tile_override) {
     narrow = (g_tile_override == 2 || g_tile_override == 4);
-    single = g_tile_override >= 3;
+    single = (g_tile_override == 3 || g_tile_override == 4 || g_tile_override == 10);
+    mixed = g_tile_override >= 9;
   }
-  g.tiles_m = tm;
-  g.tiles_n = narrow ? (N + 63) / 64 : (N + 127) / 128;
   const bool ktail = (K % BK) != 0;
-  const dim3 grid(g.tiles_m * g.tiles_n, batch);
+  if (ktail) single = mixed = false;
+  const int tn = narrow ? (N + 63) / 64 : (N + 127) / 128;
+  g.m_split = M;
+  g.big_blocks = tm128 * tn;
+  int small_blocks = 0;
+  if (mixed && batch == 1 && !narrow) {
+    // whole rounds of 128x128 tiles (2 or 3 workgroups per CU x 256 CUs); the remaining rows go to 64x64 tiles
+    const int slots = (single ? 3 : 2) * 256;
+    const int rows_per_round = (slots / tn) * 128;            // m-tile rows that fill one round
+    const int big_rows = rows_per_round > 0 ? (M / rows_per_round) * rows_per_round : 0;
+    if (big_rows <= 0 || big_rows >= M) {
+      mixed = false;
+    } else {
+      g.m_split = big_rows;
+      g.big_blocks = (big_rows / 128) * tn;
+      small_blocks = ((M - big_rows + 63) / 64) * ((N + 63) / 64);
+    }
+  } else {
+    mixed = false;
+  }
+  const dim3 grid(g.big_blocks + small_blocks, batch);
   {
     const int per_cu = single ? (narrow ? 4 : 3) : 2;
-    const long total = (long)g.tiles_m * g.tiles_n * batch;
+    const long total = (long)g.big_blocks * batch;
     g.per_cu = per_cu;
     // one tile's MFMA time alone on a CU ~ nk * 64(32 narrow) MFMAs * 64 cycles; delay resident slot s by s/per_cu of it
     const long tile_cycles = (long)((K + BK - 1) / BK) * (narrow ? 32 : 64) * 64;
-    g.stagger_cycles = (g_stagger && total >= 2L * per_cu * 256) ? (int)(tile_cycles / per_cu) : 0;
+    g.stagger_cycles = (g_stagger && !mixed && total >= 2L * per_cu * 256) ? (int)(tile_cycles / per_cu) : 0;
   }
-  if (narrow) {
-    if (ktail) gemm_f32_kernel<1, true, 2><<<grid, 256, 0, st>>>(g);
-    else if (single) gemm_f32_kernel<1, false, 1><<<grid, 256, 0, st>>>(g);
-    else gemm_f32_kernel<1, false, 2><<<grid, 256, 0, st>>>(g);
+  if (mixed) {
+    if (single) gemm_f32_kernel<2, 2, false, 1, true><<<grid, 256, 0, st>>>(g);
+    else gemm_f32_kernel<2, 2, false, 2, true><<<grid, 256, 0, st>>>(g);
+  } else if (narrow) {
+    if (ktail) gemm_f32_kernel<2, 1, true, 2, false><<<grid, 256, 0, st>>>(g);
+    else if (single) gemm_f32_kernel<2, 1, false, 1, false><<<grid, 256, 0, st>>>(g);
+    else gemm_f32_kernel<2, 1, false, 2, false><<<grid, 256, 0, st>>>(g);
   } else {
-    if (ktail) gemm_f32_kernel<2, true, 2><<<grid, 256, 0, st>>>(g);
-    else if (single) gemm_f32_kernel<2, false, 1><<<grid, 256, 0, st>>>(g);
-    else gemm_f32_kernel<2, false, 2><<<grid, 256, 0, st>>>(g);
+    if (ktail) gemm_f32_kernel<2, 2, true, 2, false><<<grid, 256, 0, st>>>(g);
+    else if (single) gemm_f32_kernel<2, 2, false, 1, false><<<grid, 256, 0, st>>>(g);
+    else gemm_f32_kernel<2, 2, false, 2, false><<<grid, 256, 0, st>>>(g);
   }
   return sgic::check_launch("gemm_f32_kernel");
 }
@@ -428,8 +447,8 @@ extern "C" int sgic_gemm_f32(const float *d_A, int lda, const float *d_W, int ld
   SGIC_REQUIRE(lda >= K, "lda");
   SGIC_REQUIRE(a_seg >= 0 && c_seg >= 0 && (a_seg == 0 || a_seg_stride >= a_seg) && (c_seg == 0 || c_seg_stride >= c_seg),
                "row segment maps");
-  GemmArgs g{d_A, d_W, d_bias, d_R, d_C, M, N, K, lda, ldw, ldr, ldc, act, 0, 0, a_seg, a_seg_stride, c_seg, c_seg_stride,
-             vec_ok(d_bias, d_R, ldr, d_C, ldc, N, 0, 0), 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  GemmArgs g{d_A, d_W, d_bias, d_R, d_C, M, N, K, lda, ldw, ldr, ldc, act, a_seg, a_seg_stride, c_seg, c_seg_stride,
+             vec_ok(d_bias, d_R, ldr, d_C, ldc, N, 0, 0), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   return gemm_launch(g, 1, to_stream(stream));
 }
 
@@ -441,8 +460,8 @@ extern "C" int sgic_gemm_batched_f32(const float *d_A, int lda, long strideA, co
   int rc = gemm_check(d_A, lda, d_W, ldw, d_bias, d_R, ldr, d_C, ldc, M, N, K, act);
   if (rc) return rc;
   SGIC_REQUIRE(lda >= K && batch > 0 && batch < 65536 && (strideA & 3) == 0 && (strideW & 3) == 0, "batch/strides");
-  GemmArgs g{d_A, d_W, d_bias, d_R, d_C, M, N, K, lda, ldw, ldr, ldc, act, 0, 0, 0, 0, 0, 0,
-             vec_ok(d_bias, d_R, ldr, d_C, ldc, N, strideC, strideR), strideA, strideW, strideC, strideR, 0, 0, 0, 0, 0};
+  GemmArgs g{d_A, d_W, d_bias, d_R, d_C, M, N, K, lda, ldw, ldr, ldc, act, 0, 0, 0, 0,
+             vec_ok(d_bias, d_R, ldr, d_C, ldc, N, strideC, strideR), strideA, strideW, strideC, strideR, 0, 0, 0, 0, 0, 0, 0};
   return gemm_launch(g, batch, to_stream(stream));
 }
 
@@ -457,7 +476,7 @@ extern "C" int sgic_conv3x3_f32(const float *d_in_halo, const float *d_W, const 
   int rc = gemm_check(d_in_halo, Cin, d_W, K, d_bias, d_R, ldr, d_out, ldc, M, Cout, K, act);
   if (rc) return rc;
   SGIC_REQUIRE(Cin % BK == 0, "implicit-GEMM conv needs Cin % 32 == 0");
-  GemmArgs g{d_in_halo, d_W, d_bias, d_R, d_out, M, Cout, K, Cin, K, ldr, ldc, act, 0, 0, 0, 0, 0, 0,
-             vec_ok(d_bias, d_R, ldr, d_out, ldc, Cout, 0, 0), 0, 0, 0, 0, Cin, H, W, 0, 0};
+  GemmArgs g{d_in_halo, d_W, d_bias, d_R, d_out, M, Cout, K, Cin, K, ldr, ldc, act, 0, 0, 0, 0,
+             vec_ok(d_bias, d_R, ldr, d_out, ldc, Cout, 0, 0), 0, 0, 0, 0, Cin, H, W, 0, 0, 0, 0};
   return gemm_launch(g, 1, to_stream(stream));
 }

@@ -35,7 +35,7 @@ def empty(*shape, like=None, dtype=torch.float32, device=None):
 # are timed with HIP events on the launch stream and the faster one is remembered.  Both tiles give bitwise
 # identical results, so tuning never changes an output.  AUTOTUNE = False uses the built-in heuristic.
 AUTOTUNE = True
-TUNE_MODES = (1, 2, 3, 4, 5, 7)   # {128x128, 128x64} x {double, single LDS buffer} (+ staggered wide variants)
+TUNE_MODES = (1, 2, 3, 4, 5, 7, 9, 10)   # {128x128, 128x64} x {double, single LDS buffer}, staggered wide, mixed 128x128 + 64x64 tail
 _TILE = {}
 
 
