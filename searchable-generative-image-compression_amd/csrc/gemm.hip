@@ -384,10 +384,10 @@ static int gemm_launch(GemmArgs g, int batch, hipStream_t st) {
   g.big_blocks = tm128 * tn;
   int small_blocks = 0;
   if (mixed && batch == 1 && !narrow) {
-    // whole rounds of 128x128 tiles (2 or 3 workgroups per CU x 256 CUs); the remaining rows go to 64x64 tiles
-    const int slots = (single ? 3 : 2) * 256;
-    const int rows_per_round = (slots / tn) * 128;            // m-tile rows that fill one round
-    const int big_rows = rows_per_round > 0 ? (M / rows_per_round) * rows_per_round : 0;
+    // 128x128 tiles for as many m-tile rows as fill whole multiples of the 256 CUs; the remaining rows (less than
+    // one CU-round of work) go to 64x64 tiles, whose finer granularity ends the launch evenly
+    const int full = ((M / 128) * tn / 256) * 256;            // big tiles in whole CU-rounds
+    const int big_rows = (full / tn) * 128;
     if (big_rows <= 0 || big_rows >= M) {
       mixed = false;
     } else {
