@@ -179,12 +179,17 @@ def main():
             x_hat = codec.decode_batch(encs)
             return [(b"", b"", b"")] * B if x_hat is not None else None
 
+    # one untimed priming step (independent of --warmup): first sight of every GEMM / attention shape runs the
+    # per-shape tile autotuner, and lazily-built tables (Swin row maps, CLIP resize coefficients, prior cache) fill
     if args.mode == "compress":
+        step()
+        drain()
         for _ in range(args.warmup):
             step()
         out = drain()
     else:
         drain = lambda: None   # noqa: E731
+        step()
         for _ in range(args.warmup):
             out = step()
 
