@@ -226,3 +226,43 @@ def test_reference_named_codec_plugin():
     assert set(enc) == {"z_bit_stream", "h_bit_stream", "img_shape", "feat_shape", "stack_shape", "token_length", "z_indices_shape"}
     x_hat = model.decode_only(**enc, clip_stream=b"", clip_meta={})
     assert x_hat.shape == (1, 3, 256, 256)
+
+
+def test_error_paths_enospc_and_bad_index(tab):
+    """slot too small -> SGIC_ENOSPC (-3) per image, index >= rows -> SGIC_EINVAL (-1); the facade retries / raises"""
+    import sgic_amd  # noqa
+    from sgic_amd._lib import call
+    from sgic_amd.entropy.MLCodec_rans import RansEncoder, _Tables
+    T = _Tables()
+    g = T.add(*tab)
+    dev = torch.device("cuda:0")
+    n = 2048
+    rng = np.random.default_rng(9)
+    idx = rng.integers(0, 256, size=(2, n)).astype(np.int16)
+    sym = rng.integers(-20000, 20000, size=(2, n)).astype(np.int16)      # bypass-heavy: ~10 bytes per symbol
+    sym[1] = 0
+    idx[1] = 0
+    d_sym, d_idx = torch.from_numpy(sym).to(dev), torch.from_numpy(idx).to(dev)
+    cap = 2 * n + 64
+    out = torch.zeros(2, cap, dtype=torch.uint8, device=dev)
+    meta = torch.zeros(3, 2, dtype=torch.int32, device=dev)
+    call("sgic_rans_encode_batch", T.handles[g], d_sym, d_idx, 2, n, out, cap, meta[0], meta[1], meta[2])
+    m = meta.cpu().numpy()
+    assert m[2, 0] == -3 and m[1, 0] == 0          # image 0 did not fit
+    assert m[2, 1] == 0 and m[1, 1] > 0            # image 1 is fine
+    # the facade retries with the hard upper bound and matches the oracle
+    enc = RansEncoder(False, 1)
+    enc.add_cdf(*tab)
+    enc.encode_with_indexes(sym[0], idx[0], 0)
+    enc.flush()
+    assert enc.get_encoded_stream().tobytes() == orc.rans_encode(sym[0], idx[0], orc.Table(*tab))
+    # bad index
+    idx_bad = idx.copy()
+    idx_bad[1, 7] = 300
+    call("sgic_rans_encode_batch", T.handles[g], d_sym, torch.from_numpy(idx_bad).to(dev), 2, n, out, 16 * n + 64 if False else cap,
+         meta[0], meta[1], meta[2])
+    assert meta.cpu().numpy()[2, 1] == -1
+    enc.reset()
+    with pytest.raises(IndexError):
+        enc.encode_with_indexes(sym[1], idx_bad[1], 0)
+        enc.flush()
