@@ -4,7 +4,7 @@ import ctypes
 
 import torch
 
-from ._lib import call, require_gpu
+from ._lib import call, lib, require_gpu
 
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_TANH, ACT_LRELU = 0, 1, 2, 3, 4
 
@@ -31,16 +31,16 @@ def empty(*shape, like=None, dtype=torch.float32, device=None):
     return torch.empty(*shape, dtype=dtype, device=like.device if like is not None else device)
 
 
-# Per-shape tile autotuning ("measure, don't guess"): the first time a GEMM shape is seen, both workgroup tiles
-# are timed with HIP events on the launch stream and the faster one is remembered.  Both tiles give bitwise
-# identical results, so tuning never changes an output.  AUTOTUNE = False uses the built-in heuristic.
+# Per-shape tile autotuning ("measure, don't guess"): the first time a GEMM / conv / attention shape is seen, every
+# launch mode of the kernel is timed with HIP events on the launch stream and the fastest is remembered.  All modes
+# give bitwise identical results (the k order is fixed), so tuning never changes an output.  AUTOTUNE = False uses
+# the built-in heuristic.  Single-threaded by design: one process per GPU, one launching thread.
 AUTOTUNE = True
 TUNE_MODES = (1, 2, 3, 4, 5, 7, 9, 10)   # {128x128, 128x64} x {double, single LDS buffer}, staggered wide, mixed 128x128 + 64x64 tail
 _TILE = {}
 
 
 def _tune(key, launch):
-    from ._lib import lib
     best, best_t = 0, None
     for mode in TUNE_MODES:
         lib.sgic_gemm_set_tile(mode)
@@ -101,8 +101,7 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if tile:
-        from ._lib import lib
-        lib.sgic_gemm_set_tile(tile)
+            lib.sgic_gemm_set_tile(tile)
     launch()
     if tile:
         lib.sgic_gemm_set_tile(0)
@@ -145,7 +144,6 @@ def attention(q, k, v, out, L, nseq, nheads, rowmap=None, bias=None, biasvar=Non
 
     # waves per workgroup (4 / 8 / 10 x 32 query rows): padding waste vs SIMD balance vs workgroups per CU depends on
     # L (measured: L=256 and 545 want 4, L=289 wants 10) -> tuned per shape like the GEMM tiles; results are identical.
-    from ._lib import lib
     mw = 10
     if AUTOTUNE:
         key = ("attn", L, nseq, nheads, bias is not None, str(q.device))
@@ -295,7 +293,6 @@ def rans_encode_batch(table, sym, idx, B, n, cap=None):
 
 
 def pack12_batch(idx_i32, B, n):
-    from ._lib import lib
     nb = lib.sgic_pack12_size(n)
     out = torch.empty(B, nb, dtype=torch.uint8, device=idx_i32.device)
     call("sgic_pack12_batch", _p(idx_i32), B, n, _p(out))
@@ -330,8 +327,7 @@ def conv3x3(x_halo, w, bias, B, H, W, Cin, Cout, residual=None, act=ACT_NONE, ou
         if tile is None:
             tile = _tune(key, launch)     # conv outputs never alias their residual: re-running is idempotent
     if tile:
-        from ._lib import lib
-        lib.sgic_gemm_set_tile(tile)
+            lib.sgic_gemm_set_tile(tile)
     launch()
     if tile:
         lib.sgic_gemm_set_tile(0)
