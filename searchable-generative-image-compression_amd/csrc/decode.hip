@@ -37,7 +37,22 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float *__restrict
   const int per = (HW + S - 1) / S, p0 = sp * per, p1 = min(HW, p0 + per);
   double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   if (pl < lanes) {
-    for (int p = p0 + pl; p < p1; p += lanes) {
+    // 4 independent loads in flight per thread (the accumulate chain is fp64; without unrolling the loop is
+    // load-latency-bound)
+    int p = p0 + pl;
+    for (; p + 3 * lanes < p1; p += 4 * lanes) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = reinterpret_cast<const f32x4 *>(x + ((long)b * HW + p + u * lanes) * C)[c4];
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          s[t] += (double)v[u][t];
+          q[t] += (double)v[u][t] * (double)v[u][t];
+        }
+    }
+    for (; p < p1; p += lanes) {
       const f32x4 v = reinterpret_cast<const f32x4 *>(x + ((long)b * HW + p) * C)[c4];
 #pragma unroll
       for (int t = 0; t < 4; t++) {
@@ -79,31 +94,36 @@ __global__ void gn_finalize_kernel(const double *__restrict__ part, int B, int H
   stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-__global__ void gn_apply_kernel(const float *__restrict__ x, const float *__restrict__ stats, const float *__restrict__ gamma,
-                                const float *__restrict__ beta, int B, int H, int W, int C, int G, int swish, int halo,
-                                float *__restrict__ y) {
+// grid = (B*H rows, chunks of the row); each thread owns one channel quad (fixed gamma/beta/stats) and walks x --
+// no integer divisions in the loop (the flat-index version was ALU-bound on its div/mod chain)
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__ x, const float *__restrict__ stats,
+                                                       const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                       int B, int H, int W, int C, int G, int swish, int halo,
+                                                       float *__restrict__ y) {
   const int C4 = C >> 2, cpg = C / G;
-  const long total = (long)B * H * W * C4;
-  GRID_STRIDE(i, total) {
-    const int c4 = (int)(i % C4);
-    long t = i / C4;
-    const int xx = (int)(t % W);
-    t /= W;
-    const int yy = (int)(t % H);
-    const int b = (int)(t / H);
-    const f32x4 v = reinterpret_cast<const f32x4 *>(x)[i];
-    const f32x4 g4 = reinterpret_cast<const f32x4 *>(gamma)[c4], b4 = reinterpret_cast<const f32x4 *>(beta)[c4];
+  const int row = blockIdx.x;            // b*H + yy
+  const int b = row / H, yy = row - b * H;
+  const int c4 = threadIdx.x % C4, xl = threadIdx.x / C4, xstep = 256 / C4;   // C4 divides 256
+  const f32x4 g4 = reinterpret_cast<const f32x4 *>(gamma)[c4], b4 = reinterpret_cast<const f32x4 *>(beta)[c4];
+  float mean[4], rstd[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int g = (c4 * 4 + e) / cpg;
+    mean[e] = stats[(b * G + g) * 2];
+    rstd[e] = stats[(b * G + g) * 2 + 1];
+  }
+  const float *xr = x + (long)row * W * C;
+  float *yr = halo ? y + (((long)b * (H + 2) + yy + 1) * (W + 2) + 1) * C : y + (long)row * W * C;
+  for (int xx = blockIdx.y * xstep + xl; xx < W; xx += gridDim.y * xstep) {
+    const f32x4 v = reinterpret_cast<const f32x4 *>(xr + (long)xx * C)[c4];
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-      const int g = (c4 * 4 + e) / cpg;
-      const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
-      float r = (v[e] - mean) * rstd * g4[e] + b4[e];
-      if (swish) r = r / (1.0f + expf(-r));  // x * sigmoid(x)
+      float r = (v[e] - mean[e]) * rstd[e] * g4[e] + b4[e];
+      if (swish) r = r / (1.0f + __expf(-r));  // x * sigmoid(x)
       o[e] = r;
     }
-    const long orow = halo ? ((long)b * (H + 2) + yy + 1) * (W + 2) + xx + 1 : ((long)b * H + yy) * W + xx;
-    reinterpret_cast<f32x4 *>(y + orow * C)[c4] = o;
+    reinterpret_cast<f32x4 *>(yr + (long)xx * C)[c4] = o;
   }
 }
 
@@ -118,8 +138,12 @@ extern "C" int sgic_groupnorm_nhwc(const float *d_x, const float *d_gamma, const
   hipStream_t st = to_stream(stream);
   gn_partial_kernel<<<B * S, 256, 256 * 8 * sizeof(double), st>>>(d_x, HW, C, S, d_ws);
   gn_finalize_kernel<<<cdiv((size_t)B * groups, 64), 64, 0, st>>>(d_ws, B, HW, C, S, groups, eps, d_stats);
-  gn_apply_kernel<<<ew_grid((long)B * HW * C / 4), 256, 0, st>>>(d_x, d_stats, d_gamma, d_beta, B, H, W, C, groups, swish,
-                                                                 halo_out, d_y);
+  {
+    const int xstep = 256 / (C / 4);
+    int chunks = (W + xstep * 8 - 1) / (xstep * 8);   // ~8 positions per thread
+    chunks = chunks < 1 ? 1 : chunks;
+    gn_apply_kernel<<<dim3(B * H, chunks), 256, 0, st>>>(d_x, d_stats, d_gamma, d_beta, B, H, W, C, groups, swish, halo_out, d_y);
+  }
   return sgic::check_launch("groupnorm");
 }
 
