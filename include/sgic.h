@@ -214,6 +214,14 @@ int sgic_nhwc3_to_nchw_clamp(const float *d_in, int ld, int B, int H, int W, flo
  * (nq, n) = sgic_gemm_f32(queries, database) and is consumed (taken entries become -inf). */
 int sgic_topk_rows(float *d_scores, int nq, int n, int k, float *d_out_scores, int32_t *d_out_idx, sgic_stream_t stream);
 
+/* CLIP text tower front end: out[b*L+l,:] = table[ids[b,l],:] + pos[l,:] (open_clip CLIP.encode_text, reached from
+ * search.py:93-97; ids outside [0,vocab) are clamped).  D multiple of 4. */
+int sgic_embed_tokens(const int32_t *d_ids, const float *d_table, const float *d_pos, float *d_out, int B, int L, int D,
+                      int vocab, sgic_stream_t stream);
+/* CLIP text pooling: out[b,:] = x[b*L + argmax_l ids[b,l], :] (first maximum = the EOT token, the largest BPE id). */
+int sgic_gather_eot_rows(const int32_t *d_ids, const float *d_x, int ldx, float *d_out, int B, int L, int D,
+                         sgic_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

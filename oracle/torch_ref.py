@@ -18,8 +18,8 @@ import torch.nn.functional as F
 # ---------------------------------------------------------------------------------------------
 # building blocks
 # ---------------------------------------------------------------------------------------------
-def mha(x, sd, p, heads):
-    """nn.MultiheadAttention self-attention, (L, N, D) layout (titok/blocks.py:50-54)"""
+def mha(x, sd, p, heads, mask=None):
+    """nn.MultiheadAttention self-attention, (L, N, D) layout (titok/blocks.py:50-54); mask: additive (L, L)"""
     L, N, D = x.shape
     hd = D // heads
     qkv = F.linear(x, sd[f"{p}.in_proj_weight"], sd[f"{p}.in_proj_bias"])
@@ -27,15 +27,18 @@ def mha(x, sd, p, heads):
     q = q.reshape(L, N * heads, hd).transpose(0, 1) * (hd ** -0.5)
     k = k.reshape(L, N * heads, hd).transpose(0, 1)
     v = v.reshape(L, N * heads, hd).transpose(0, 1)
-    a = torch.softmax(q @ k.transpose(1, 2), dim=-1) @ v
+    s = q @ k.transpose(1, 2)
+    if mask is not None:
+        s = s + mask
+    a = torch.softmax(s, dim=-1) @ v
     a = a.transpose(0, 1).reshape(L, N, D)
     return F.linear(a, sd[f"{p}.out_proj.weight"], sd[f"{p}.out_proj.bias"])
 
 
-def rab(x, sd, p, heads):
+def rab(x, sd, p, heads, mask=None):
     """ResidualAttentionBlock (titok/blocks.py:56-64)"""
     D = x.shape[-1]
-    x = x + mha(F.layer_norm(x, (D,), sd[f"{p}.ln_1.weight"], sd[f"{p}.ln_1.bias"]), sd, f"{p}.attn", heads)
+    x = x + mha(F.layer_norm(x, (D,), sd[f"{p}.ln_1.weight"], sd[f"{p}.ln_1.bias"]), sd, f"{p}.attn", heads, mask)
     h = F.layer_norm(x, (D,), sd[f"{p}.ln_2.weight"], sd[f"{p}.ln_2.bias"])
     h = F.linear(F.gelu(F.linear(h, sd[f"{p}.mlp.c_fc.weight"], sd[f"{p}.mlp.c_fc.bias"])),
                  sd[f"{p}.mlp.c_proj.weight"], sd[f"{p}.mlp.c_proj.bias"])
@@ -271,6 +274,22 @@ def clip_tower(x, sd, cfg, p="clip.visual"):
     x = x.permute(1, 0, 2)
     pooled = F.layer_norm(x[:, 0], (Wd,), sd[f"{p}.ln_post.weight"], sd[f"{p}.ln_post.bias"])
     z = pooled @ sd[f"{p}.proj"]
+    return z / z.norm(dim=-1, keepdim=True)
+
+
+def clip_text_tower(tokens, sd, cfg, p="clip"):
+    """open_clip CLIP.encode_text as search.py:93-97 calls it (third-party, restated from its published definition):
+    tokens (B, ctx) int -> unit-norm (B, embed_dim).  Pinned against the independent HuggingFace `transformers` CLIP
+    implementation (same synthetic weights) by tests/test_oracle_clip_hf.py."""
+    Wd, L = cfg.t_width, cfg.ctx
+    tokens = torch.as_tensor(tokens).long()
+    x = sd[f"{p}.token_embedding.weight"][tokens] + sd[f"{p}.positional_embedding"]
+    mask = torch.full((L, L), float("-inf")).triu_(1)
+    x = x.permute(1, 0, 2)
+    for i in range(cfg.t_layers):
+        x = rab(x, sd, f"{p}.transformer.resblocks.{i}", cfg.t_heads, mask)
+    x = F.layer_norm(x.permute(1, 0, 2), (Wd,), sd[f"{p}.ln_final.weight"], sd[f"{p}.ln_final.bias"])
+    z = x[torch.arange(x.shape[0]), tokens.argmax(dim=-1)] @ sd[f"{p}.text_projection"]
     return z / z.norm(dim=-1, keepdim=True)
 
 

@@ -126,3 +126,44 @@ class ClipHIP:
 
     def encode(self, x, H=None, W=None):
         return self.tower(self.preprocess(x, H, W))
+
+
+class ClipTextHIP:
+    """OpenCLIP text tower (search.py:54-55,93-97 -> open_clip CLIP.encode_text; third-party, architecture restated
+    from its published definition): token embedding + learned positions, `t_layers` pre-LN residual attention blocks
+    with a causal additive mask, ln_final, the row of the EOT token (argmax of the ids) times text_projection.
+    Tokenisation stays with the caller (open_clip's BPE vocabulary is not part of the reference tree)."""
+
+    def __init__(self, sd, cfg: ClipConfig, device, p="clip"):
+        self.cfg, self.device = cfg, device
+        g = lambda k: sd[f"{p}.{k}"].to(device=device, dtype=torch.float32).contiguous()
+        self.table, self.pos = g("token_embedding.weight"), g("positional_embedding")
+        self.blocks = [RabW(sd, f"{p}.transformer.resblocks.{i}", device) for i in range(cfg.t_layers)]
+        self.lnf_w, self.lnf_b = g("ln_final.weight"), g("ln_final.bias")
+        self.projT = sd[f"{p}.text_projection"].t().to(device=device, dtype=torch.float32).contiguous()   # (embed_dim, width)
+        # the attention kernel reads its bias in float4s (L % 4 == 0): run on ctx rounded up to a multiple of 4; under
+        # the causal mask the extra trailing positions (id 0, zero position row) cannot reach the real ones.
+        L = self.L = (cfg.ctx + 3) & ~3
+        if L != cfg.ctx:
+            self.pos = torch.cat([self.pos, torch.zeros(L - cfg.ctx, cfg.t_width, device=device)]).contiguous()
+        self.causal = torch.full((L, L), float("-inf")).triu_(1).reshape(1, L, L).to(device).contiguous()
+
+    def encode_text(self, tokens):
+        """tokens: int tensor/array (B, ctx) -> (unit fp32 (B, embed_dim) on the device)"""
+        cfg = self.cfg
+        ids = torch.as_tensor(np.asarray(tokens.cpu() if torch.is_tensor(tokens) else tokens)).to(torch.int32)
+        if ids.dim() != 2 or ids.shape[1] != cfg.ctx:
+            raise ValueError(f"tokens must be (B, {cfg.ctx}), got {tuple(ids.shape)}")
+        if self.L != cfg.ctx:
+            ids = torch.nn.functional.pad(ids, (0, self.L - cfg.ctx))
+        ids = ids.to(self.device).contiguous()
+        B, L, D = ids.shape[0], self.L, cfg.t_width
+        X = torch.empty(B * L, D, dtype=torch.float32, device=self.device)
+        call("sgic_embed_tokens", ops._p(ids), ops._p(self.table), ops._p(self.pos), ops._p(X), B, L, D, cfg.vocab)
+        for w in self.blocks:
+            rab_forward(X, w, L, B, cfg.t_heads, bias=self.causal)
+        pooled = torch.empty(B, D, dtype=torch.float32, device=self.device)
+        call("sgic_gather_eot_rows", ops._p(ids), ops._p(X), D, ops._p(pooled), B, L, D)
+        ops.layernorm(pooled, self.lnf_w, self.lnf_b, out=pooled)
+        z = ops.gemm(pooled, self.projT)
+        return ops.l2norm_u8(z)[0]

@@ -37,7 +37,10 @@ def load_state(path, spec_fn, cfg, seed):
     from . import weights as W
     if path:
         sd = torch.load(path, map_location="cpu", weights_only=True)
-        return sd.get("state_dict", sd)
+        sd = sd.get("state_dict", sd)
+        if "visual.conv1.weight" in sd or "token_embedding.weight" in sd:   # a bare open_clip CLIP state_dict
+            sd = {f"clip.{k}": v for k, v in sd.items()}
+        return sd
     return W.synth_weights(spec_fn(cfg), seed=seed)
 
 

@@ -71,16 +71,21 @@ SMALL = CodecConfig(model_size="small", feat_dim=256, in_pos_enc=(1, 5), in_pos_
 
 @dataclass(frozen=True)
 class ClipConfig:
-    """OpenCLIP ViT-B-32 image tower (compress.py:59-63)."""
+    """OpenCLIP ViT-B-32: image tower (compress.py:59-63) and text tower (search.py:54-55,93-97)."""
     image_size: int = 224
     patch: int = 32
     width: int = 768
     layers: int = 12
     heads: int = 12
     embed_dim: int = 512
+    vocab: int = 49408          # text tower: BPE vocabulary, context length, transformer width/heads/layers
+    ctx: int = 77
+    t_width: int = 512
+    t_heads: int = 8
+    t_layers: int = 12
     mean: Tuple[float, float, float] = (0.48145466, 0.4578275, 0.40821073)
     std: Tuple[float, float, float] = (0.26862954, 0.26130258, 0.27577711)
 
 
 CLIP_B32 = ClipConfig()
-CLIP_TINY = ClipConfig(width=128, layers=2, heads=2, embed_dim=64)
+CLIP_TINY = ClipConfig(width=128, layers=2, heads=2, embed_dim=64, vocab=512, ctx=16, t_width=128, t_heads=2, t_layers=2)

@@ -4,6 +4,7 @@
 // tile <-> stack rearranges (models/codec_sq_fixbpp.py:123-125, models/cross_blocks.py:78-79,96-97)
 // the identity, so no gather/scatter pass is ever needed.
 #include "common.h"
+#include <limits.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -454,4 +455,57 @@ extern "C" int sgic_l2norm_u8(const float *d_x, int ldx, int M, int D, float *d_
   SGIC_REQUIRE(d_x && d_unit && d_q && M > 0 && D > 0 && ldx >= D, "args");
   l2norm_u8_kernel<<<cdiv(M, 4), 256, 0, to_stream(stream)>>>(d_x, ldx, M, D, d_unit, d_q);
   return sgic::check_launch("l2norm_u8_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// CLIP text tower front / back ends (open_clip CLIP.encode_text, called from search.py:93-97):
+//   embed:  out[b*L + l, :] = table[clamp(ids[b*L + l]), :] + pos[l, :]
+//   pool :  out[b, :] = x[b*L + argmax_l ids[b, l], :]   (first maximum, like torch.argmax: the EOT token
+//           has the largest id of the BPE vocabulary)
+// ------------------------------------------------------------------------------------------------
+__global__ void embed_tokens_kernel(const int *__restrict__ ids, const float *__restrict__ table,
+                                    const float *__restrict__ pos, float *__restrict__ out, int B, int L, int D, int vocab) {
+  const int D4 = D >> 2;
+  const long total = (long)B * L * D4;
+  GRID_STRIDE(i, total) {
+    const int d4 = (int)(i % D4);
+    const long r = i / D4;
+    const int l = (int)(r % L);
+    int id = ids[r];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const f32x4 a = reinterpret_cast<const f32x4 *>(table + (long)id * D)[d4];
+    const f32x4 p = reinterpret_cast<const f32x4 *>(pos + (long)l * D)[d4];
+    reinterpret_cast<f32x4 *>(out + r * D)[d4] = a + p;
+  }
+}
+
+extern "C" int sgic_embed_tokens(const int *d_ids, const float *d_table, const float *d_pos, float *d_out, int B, int L,
+                                 int D, int vocab, sgic_stream_t stream) {
+  SGIC_REQUIRE(d_ids && d_table && d_pos && d_out && B > 0 && L > 0 && D > 0 && (D & 3) == 0 && vocab > 0, "args");
+  const long total = (long)B * L * (D / 4);
+  embed_tokens_kernel<<<ew_grid(total), 256, 0, to_stream(stream)>>>(d_ids, d_table, d_pos, d_out, B, L, D, vocab);
+  return sgic::check_launch("embed_tokens_kernel");
+}
+
+__global__ __launch_bounds__(64) void gather_eot_rows_kernel(const int *__restrict__ ids, const float *__restrict__ x,
+                                                              int ldx, float *__restrict__ out, int L, int D) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int best = INT_MIN, pos = 0;
+  for (int l = lane; l < L; l += 64) {  // ascending l per lane => strict '>' keeps the first maximum
+    const int v = ids[(long)b * L + l];
+    if (v > best) { best = v; pos = l; }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const int ob = __shfl_xor(best, o), op = __shfl_xor(pos, o);
+    if (ob > best || (ob == best && op < pos)) { best = ob; pos = op; }
+  }
+  const float *src = x + ((long)b * L + pos) * ldx;
+  for (int d = lane; d < D; d += 64) out[(long)b * D + d] = src[d];
+}
+
+extern "C" int sgic_gather_eot_rows(const int *d_ids, const float *d_x, int ldx, float *d_out, int B, int L, int D,
+                                    sgic_stream_t stream) {
+  SGIC_REQUIRE(d_ids && d_x && d_out && B > 0 && L > 0 && D > 0 && ldx >= D, "args");
+  gather_eot_rows_kernel<<<B, 64, 0, to_stream(stream)>>>(d_ids, d_x, ldx, d_out, L, D);
+  return sgic::check_launch("gather_eot_rows_kernel");
 }

@@ -33,13 +33,13 @@ class RabW:
         self.pjw, self.pjb = g("mlp.c_proj.weight"), g("mlp.c_proj.bias")
 
 
-def rab_forward(X, w: RabW, L, nseq, heads):
-    """in place on X [(nseq*L), D]"""
+def rab_forward(X, w: RabW, L, nseq, heads, bias=None):
+    """in place on X [(nseq*L), D]; bias: optional (1,L,L) additive attention mask (CLIP text tower: causal)"""
     D = X.shape[1]
     h = ops.layernorm(X, w.ln1w, w.ln1b)
     qkv = ops.gemm(h, w.inw, w.inb)
     att = h  # reuse the LN buffer for the attention output
-    ops.attention(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], att, L, nseq, heads)
+    ops.attention(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], att, L, nseq, heads, bias=bias)
     ops.gemm(att, w.ow, w.ob, residual=X, out=X)
     ops.layernorm(X, w.ln2w, w.ln2b, out=h)
     f = ops.gemm(h, w.fcw, w.fcb, act=ops.ACT_GELU)

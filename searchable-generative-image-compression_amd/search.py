@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Counterpart of the reference src/search.py: query a FAISS IndexFlatIP built by compress.py.
 `query-c2df` needs no CLIP model (zstd-decode the embedded u8 code, q/255*2-1, l2-normalise; search.py:20-41);
-`query-image` runs the MI355X CLIP tower; `query-text` needs the CLIP text tower, which is outside this round's
-scope and raises.  The search itself is exact inner product: one fp32 MFMA GEMM (queries x
+`query-image` / `query-text` run the MI355X CLIP image / text towers (clip.py).  The BPE tokenizer is open_clip's
+(third-party, its vocabulary file is not in the reference tree): `query-text` uses `open_clip.get_tokenizer` when the
+package is importable and otherwise takes ready-made ids via --token_ids.  The search itself is exact inner product: one fp32 MFMA GEMM (queries x
 database^T) + a top-k kernel on the GPU."""
 import argparse
 import json
@@ -52,6 +53,28 @@ def load_index(index_dir):
     return vecs, paths
 
 
+def tokenize(text, ctx=77, token_ids=None):
+    """search.py:93-94 `tokenizer([query])` -> (1, ctx) int64.  open_clip's tokenizer when available; `token_ids`
+    (already BPE-encoded, <start> ... <end>) is the offline route."""
+    if token_ids is not None:
+        ids = [int(t) for t in (token_ids.split(",") if isinstance(token_ids, str) else token_ids)]
+        if not 0 < len(ids) <= ctx:
+            raise ValueError(f"need 1..{ctx} token ids, got {len(ids)}")
+        out = np.zeros((1, ctx), dtype=np.int64)
+        out[0, :len(ids)] = ids
+        return out
+    try:
+        import open_clip
+    except ImportError as e:
+        raise RuntimeError("query-text needs open_clip's BPE tokenizer (pip package open_clip_torch) or --token_ids") from e
+    return np.asarray(open_clip.get_tokenizer("ViT-B-32")([text]), dtype=np.int64)
+
+
+def encode_text(tokens, text_model):
+    """search.py:92-97 encode_text: unit-norm (1, D) fp32 on the host"""
+    return text_model.encode_text(tokens).cpu().numpy().astype("float32")
+
+
 def search_gpu(q, vecs, topk, device="cuda:0"):
     """exact IndexFlatIP.search on the GPU: -> (scores (nq,k), ids (nq,k))"""
     from . import ops
@@ -78,6 +101,8 @@ def main(argv=None):
         p.add_argument(arg, type=str, required=True)
         p.add_argument("--topk", type=int, default=10)
         p.add_argument("--clip_ckpt", type=str, default=None)
+        if name == "query-text":
+            p.add_argument("--token_ids", type=str, default=None, help="comma-separated BPE ids (offline tokenizer bypass)")
     args = ap.parse_args(argv)
     vecs, paths = load_index(args.index_dir)
     if args.cmd == "query-c2df":
@@ -90,7 +115,13 @@ def main(argv=None):
         csd = load_state(args.clip_ckpt, W.clip_spec, CLIP_B32, 4321)
         q = ClipCodec(csd, CLIP_B32, "cuda:0").image_to_unit_vec(load_image(args.image))[None, :]
     else:
-        raise NotImplementedError("query-text needs the CLIP text tower (SURVEY §8f-1: next scope row)")
+        from . import weights as W
+        from .clip import ClipTextHIP
+        from .compress import load_state
+        from .config import CLIP_B32
+        toks = tokenize(args.text, CLIP_B32.ctx, args.token_ids)
+        tsd = load_state(args.clip_ckpt, W.clip_text_spec, CLIP_B32, 4321)
+        q = encode_text(toks, ClipTextHIP(tsd, CLIP_B32, "cuda:0"))
     print(json.dumps([{"path": p, "score": s} for p, s in do_search(q, vecs, paths, args.topk)], ensure_ascii=False, indent=2))
     return 0
 

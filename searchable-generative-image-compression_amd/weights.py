@@ -238,6 +238,18 @@ def clip_spec(cfg: ClipConfig, prefix="clip.visual"):
     return o
 
 
+def clip_text_spec(cfg: ClipConfig, prefix="clip"):
+    """open_clip CLIP text-tower state_dict names (token_embedding, positional_embedding, transformer,
+    ln_final, text_projection)"""
+    W = cfg.t_width
+    o = [(f"{prefix}.token_embedding.weight", (cfg.vocab, W), "emb"), (f"{prefix}.positional_embedding", (cfg.ctx, W), "emb")]
+    for i in range(cfg.t_layers):
+        _rab(f"{prefix}.transformer.resblocks.{i}", W, o)
+    o += [(f"{prefix}.ln_final.weight", (W,), "ln_w"), (f"{prefix}.ln_final.bias", (W,), "ln_b"),
+          (f"{prefix}.text_projection", (W, cfg.embed_dim), "proj")]
+    return o
+
+
 def create_mask(window_size, displacement, upper_lower, left_right):
     """the constant -inf shift masks the reference stores as Parameters (swin_transformer.py:42-55)"""
     w = window_size

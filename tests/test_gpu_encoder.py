@@ -188,3 +188,40 @@ def test_clip_tower_vs_torch_ref():
     assert float(cos.min()) > 0.99999 and float((unit.cpu() - ref).abs().max()) < 1e-4
     qref = np.clip(np.round((ref.numpy() * 0.5 + 0.5) * 255.0), 0, 255).astype(np.uint8)
     assert float((q.cpu().numpy() != qref).mean()) <= 0.01
+
+
+def _clip_tokens(cfg, lens, seed):
+    """open_clip layout: <start> words... <end>, zero padded; <end> = vocab-1 is the largest id"""
+    rng = np.random.default_rng(seed)
+    toks = np.zeros((len(lens), cfg.ctx), dtype=np.int64)
+    for b, n in enumerate(lens):
+        toks[b, 0] = cfg.vocab - 2
+        toks[b, 1:1 + n] = rng.integers(1, cfg.vocab - 2, n)
+        toks[b, 1 + n] = cfg.vocab - 1
+    return toks
+
+
+@pytest.mark.parametrize("name", ["tiny", "b32"])
+def test_clip_text_tower_vs_torch_ref(name):
+    """CLIP text tower (search.py:93-97 -> open_clip encode_text): HIP vs the torch oracle, which
+    tests/test_oracle_clip_hf.py pins against HuggingFace's CLIP.  Tolerance: cosine > 0.99999, max abs 1e-4 on unit vectors."""
+    import sgic_amd  # noqa
+    from sgic_amd import weights as W
+    from sgic_amd.clip import ClipTextHIP
+    from sgic_amd.config import CLIP_B32, CLIP_TINY
+    cfg = CLIP_TINY if name == "tiny" else CLIP_B32
+    sd = W.synth_weights(W.clip_text_spec(cfg), seed=6)
+    model = ClipTextHIP(sd, cfg, torch.device("cuda:0"))
+    toks = _clip_tokens(cfg, (1, 5, cfg.ctx - 2, 9, 0), 3)
+    unit = model.encode_text(toks).cpu()
+    with torch.no_grad():
+        ref = TR.clip_text_tower(toks, sd, cfg)
+    cos = torch.nn.functional.cosine_similarity(unit, ref, dim=-1)
+    print("clip text cosine", cos.tolist(), "max abs err", float((unit - ref).abs().max()))
+    assert float(cos.min()) > 0.99999 and float((unit - ref).abs().max()) < 1e-4
+    # the padding after <end> must not matter (causal mask): same prompt, garbage after EOT -> same vector
+    t2 = toks.copy()
+    t2[1, 8:] = 7
+    assert torch.equal(model.encode_text(t2).cpu()[1], unit[1])
+    with pytest.raises(ValueError):
+        model.encode_text(toks[:, :-1])

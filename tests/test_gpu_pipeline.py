@@ -43,6 +43,11 @@ def test_compress_search_decompress_cli(tmp_path):
     ref = np.argsort(-(q[None] @ vecs.T), axis=1, kind="stable")[:, :5]
     assert i[0, 0] == 3 and np.array_equal(i, ref)
     assert np.allclose(s[0], (q[None] @ vecs.T)[0, ref[0]], atol=1e-5)
+    # query-text plumbing: tokenizer bypass -> text tower -> top-k (synthetic weights: ranks are arbitrary, shapes are not)
+    with pytest.raises(ValueError):
+        search.tokenize("x", 77, ",".join(["1"] * 78))
+    toks = search.tokenize("ignored", 77, "49406,320,1125,49407")
+    assert toks.shape == (1, 77) and toks[0, 3] == 49407 and toks[0, 4:].sum() == 0
     # decompress
     assert decompress.main(["--dataset_dir", str(out / "bitstreams"), "--save_dir", str(out), "--small"]) == 0
     for i, (h, w) in enumerate(sizes):
