@@ -69,6 +69,20 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
+template <int ACT>
+__device__ __forceinline__ float apply_act_c(float v) {
+  if constexpr (ACT == ACT_GELU) return 0.5f * v * (1.0f + fast_erf(v * 0.70710678118654752440f));
+  else if constexpr (ACT == ACT_SILU) return v / (1.0f + expf(-v));
+  else if constexpr (ACT == ACT_TANH) return tanhf(v);
+  else if constexpr (ACT == ACT_LRELU) return v >= 0.f ? v : 0.01f * v;
+  else return v;
+}
+
+template <int V>
+struct IntC {
+  static constexpr int value = V;
+};
+
 struct GemmArgs {
   const float *A;
   const float *W;
@@ -94,9 +108,12 @@ struct GemmArgs {
   int m_split, big_blocks;
 };
 
-// One output tile.  bid = workgroup index inside its region, rows [row_base, row_end) x all N.
-template <int WM, int WN, bool KTAIL, int NBUF>
-__device__ __forceinline__ void gemm_tile(const GemmArgs &g, int bid, int row_base, int row_end, float *smem) {
+// Output tiles of one workgroup.  bid = workgroup index inside its region, rows [row_base, row_end) x all N.
+// PERSIST: the workgroup walks tiles bid, bid + step, ... ; the next tile's first K slice is requested BEFORE the
+// current tile's epilogue, so the store phase, the workgroup hand-over and the first-load latency of a
+// one-tile-per-workgroup launch disappear from the MFMA pipe's critical path.
+template <int WM, int WN, bool KTAIL, int NBUF, bool PERSIST>
+__device__ __forceinline__ void gemm_tile(const GemmArgs &g, int bid, int step, int row_base, int row_end, float *smem) {
   constexpr int TBM = 64 * WM, TBN = 64 * WN;       // workgroup tile
   constexpr int NA4 = TBM / 32, NB4 = TBN / 32;     // float4 staged per thread (rows x 8 chunks / 256 threads)
   float(*sA)[TBM * LDS_LD] = reinterpret_cast<float(*)[TBM * LDS_LD]>(smem);
@@ -107,16 +124,18 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, int bid, int row_ba
   // workgroups resident on one XCD cover an ~8x8 patch of tiles and reuse each other's A / W k-slices in L2.
   const int tiles_m = (row_end - row_base + TBM - 1) / TBM, tiles_n = (g.N + TBN - 1) / TBN;
   const int nwg = tiles_m * tiles_n;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, within = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
-  }
-  constexpr int GROUP_M = 8;
-  const int per_group = GROUP_M * tiles_n;
-  const int group = bid / per_group, first_m = group * GROUP_M;
-  const int gsz = min(tiles_m - first_m, GROUP_M);
-  const int in_group = bid - group * per_group;
-  const int m0 = row_base + (first_m + in_group % gsz) * TBM, n0 = (in_group / gsz) * TBN;
+  int m0, n0;
+  auto locate = [&](int t) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = t & 7, within = t >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * tiles_n;
+    const int group = t / per_group, first_m = group * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int in_group = t - group * per_group;
+    m0 = row_base + (first_m + in_group % gsz) * TBM;
+    n0 = (in_group / gsz) * TBN;
+  };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * (32 * WM), wn = (wave & 1) * (32 * WN);
@@ -124,23 +143,28 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, int bid, int row_ba
   f32x4 ra[NA4], rb[NB4];
   const float *aptr[NA4];
   const float *wptr[NB4];
+  auto setup = [&]() {
 #pragma unroll
-  for (int i = 0; i < NA4; i++) {
-    const int am = min(m0 + srow + 32 * i, g.M - 1);
-    size_t arow;
-    if (g.conv_C) {  // top-left pixel of the 3x3 patch in the halo buffer
-      const int hw = g.conv_H * g.conv_W, b = am / hw, r = am - b * hw, y = r / g.conv_W, x = r - y * g.conv_W;
-      arow = ((size_t)b * (g.conv_H + 2) + y) * (g.conv_W + 2) + x;
-    } else {
-      arow = g.a_seg ? (size_t)(am / g.a_seg) * g.a_seg_stride + (am % g.a_seg) : (size_t)am;
+    for (int i = 0; i < NA4; i++) {
+      const int am = min(m0 + srow + 32 * i, g.M - 1);
+      size_t arow;
+      if (g.conv_C) {  // top-left pixel of the 3x3 patch in the halo buffer
+        const int hw = g.conv_H * g.conv_W, b = am / hw, r = am - b * hw, y = r / g.conv_W, x = r - y * g.conv_W;
+        arow = ((size_t)b * (g.conv_H + 2) + y) * (g.conv_W + 2) + x;
+      } else {
+        arow = g.a_seg ? (size_t)(am / g.a_seg) * g.a_seg_stride + (am % g.a_seg) : (size_t)am;
+      }
+      aptr[i] = g.A + arow * g.lda;
     }
-    aptr[i] = g.A + arow * g.lda;
-  }
 #pragma unroll
-  for (int i = 0; i < NB4; i++) {
-    const int wr = min(n0 + srow + 32 * i, g.N - 1);
-    wptr[i] = g.W + (size_t)wr * g.ldw;
-  }
+    for (int i = 0; i < NB4; i++) {
+      const int wr = min(n0 + srow + 32 * i, g.N - 1);
+      wptr[i] = g.W + (size_t)wr * g.ldw;
+    }
+  };
+  if (PERSIST && bid >= nwg) return;
+  locate(bid);
+  setup();
 
   // KTAIL = false (K % 32 == 0, every large GEMM of the model): plain loads whose results are first touched by
   // the ds_write one K-step later, so their latency hides under a full MFMA phase.  KTAIL = true: the tail chunk
@@ -181,13 +205,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, int bid, int row_ba
   };
 
   f32x16 acc[WM][WN];
-#pragma unroll
-  for (int i = 0; i < WM; i++)
-#pragma unroll
-    for (int j = 0; j < WN; j++)
-#pragma unroll
-      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
-
   const int lrow = lane & 31, lhalf = lane >> 5;
   const int aoff = (wm + lrow) * LDS_LD + lhalf * 4;
   const int boff = (wn + lrow) * LDS_LD + lhalf * 4;
@@ -221,113 +238,175 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, int bid, int row_ba
     }
   }
   Frag f0, f1;
-  if constexpr (NBUF == 2) {
-    issue_loads(0);
-    store_lds(0);
-    if (nk > 1) issue_loads(BK);
-    __syncthreads();
-    read_frag(f0, 0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1, nxt = cur ^ 1;
-      if (kt + 1 < nk) {
-        store_lds(nxt);  // tile kt+1; buffer nxt was last read before the previous step's barrier
-        if (kt + 2 < nk) issue_loads((kt + 2) * BK);
-      }
-      read_frag(f1, cur, 1);
-      mfma_frag(f0);
-      read_frag(f0, cur, 2);
-      mfma_frag(f1);
-      read_frag(f1, cur, 3);
-      mfma_frag(f0);
-      // one barrier per K-step: LDS traffic only (the staged global loads stay in flight across it)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (kt + 1 < nk) read_frag(f0, nxt, 0);
-      mfma_frag(f1);
-    }
-  } else {
-    issue_loads(0);
-    for (int kt = 0; kt < nk; ++kt) {
-      store_lds(0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (kt + 1 < nk) issue_loads((kt + 1) * BK);  // in flight during the MFMA phase below
-      read_frag(f0, 0, 0);
-      read_frag(f1, 0, 1);
-      mfma_frag(f0);
-      read_frag(f0, 0, 2);
-      mfma_frag(f1);
-      read_frag(f1, 0, 3);
-      mfma_frag(f0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // everyone done reading before the next store
-      mfma_frag(f1);
-    }
-    __syncthreads();  // epilogue reuses the staging LDS
-  }
-
-  // ---- epilogue.  Accumulator layout: D[row = (e&3) + 8*(e>>2) + 4*lhalf][col = lrow] ----
-  if (g.vec_epilogue) {
-    // Wide stores: each wave transposes its accumulators 32 rows at a time through its private LDS slice (nobody
-    // reads the staging buffers after the last barrier) and writes whole 128/256-byte row segments as dwordx4 --
-    // 4x fewer store instructions than one dword per lane, which is what bounds a lock-stepped epilogue.
-    constexpr int TW = 32 * WN;            // wave tile width (floats)
-    constexpr int LPR = TW / 4;            // lanes per row (float4 each)
-    constexpr int RPI = 64 / LPR;          // rows per store instruction
-    float *ep = smem + wave * (32 * TW);
-    const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
-    const int n = n0 + wn + c4;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (g.bias && n < g.N) bv = *reinterpret_cast<const f32x4 *>(g.bias + n);
+  issue_loads(0);
+  for (;;) {
 #pragma unroll
-    for (int i = 0; i < WM; i++) {
+    for (int i = 0; i < WM; i++)
 #pragma unroll
       for (int j = 0; j < WN; j++)
 #pragma unroll
-        for (int e = 0; e < 16; e++) ep[((e & 3) + 8 * (e >> 2) + 4 * lhalf) * TW + j * 32 + lrow] = acc[i][j][e];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (n < g.N) {  // N % 4 == 0 in this path, so a float4 is all-in or all-out
+        for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+    if constexpr (NBUF == 2) {
+      store_lds(0);
+      if (nk > 1) issue_loads(BK);
+      __syncthreads();
+      read_frag(f0, 0, 0);
+      for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1, nxt = cur ^ 1;
+        if (kt + 1 < nk) {
+          store_lds(nxt);  // tile kt+1; buffer nxt was last read before the previous step's barrier
+          if (kt + 2 < nk) issue_loads((kt + 2) * BK);
+        }
+        read_frag(f1, cur, 1);
+        mfma_frag(f0);
+        read_frag(f0, cur, 2);
+        mfma_frag(f1);
+        read_frag(f1, cur, 3);
+        mfma_frag(f0);
+        // one barrier per K-step: LDS traffic only (the staged global loads stay in flight across it)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) read_frag(f0, nxt, 0);
+        mfma_frag(f1);
+      }
+    } else {
+      for (int kt = 0; kt < nk; ++kt) {
+        store_lds(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) issue_loads((kt + 1) * BK);  // in flight during the MFMA phase below
+        read_frag(f0, 0, 0);
+        read_frag(f1, 0, 1);
+        mfma_frag(f0);
+        read_frag(f0, 0, 2);
+        mfma_frag(f1);
+        read_frag(f1, 0, 3);
+        mfma_frag(f0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // everyone done reading before the next store
+        mfma_frag(f1);
+      }
+      __syncthreads();  // epilogue reuses the staging LDS
+    }
+
+    // the tile being finished, and (PERSIST) the next one: its first K slice is in flight during the epilogue
+    const int em0 = m0, en0 = n0;
+    bool more = false;
+    if constexpr (PERSIST) {
+      bid += step;
+      more = bid < nwg;
+      if (more) {
+        locate(bid);
+        setup();
+        issue_loads(0);
+      }
+    }
+
+    // ---- epilogue.  Accumulator layout: D[row = (e&3) + 8*(e>>2) + 4*lhalf][col = lrow] ----
+    if (g.vec_epilogue) {
+      // Wide stores: each wave transposes its accumulators 32 rows at a time through its private LDS slice (nobody
+      // reads the staging buffers after the last barrier) and writes whole 128/256-byte row segments as dwordx4 --
+      // 4x fewer store instructions than one dword per lane, which is what bounds a lock-stepped epilogue.
+      // The activation / residual / row-map choices are hoisted out of the store loop (one straight-line variant
+      // each): as per-element uniform branches they cost more than the stores themselves.
+      constexpr int TW = 32 * WN;            // wave tile width (floats)
+      constexpr int LPR = TW / 4;            // lanes per row (float4 each)
+      constexpr int RPI = 64 / LPR;          // rows per store instruction
+      float *ep = smem + wave * (32 * TW);
+      const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
+      const int n = en0 + wn + c4;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (g.bias && n < g.N) bv = *reinterpret_cast<const f32x4 *>(g.bias + n);
+      auto run = [&](auto act_c, auto res_c, auto map_c) {
+        constexpr int ACT = decltype(act_c)::value;
+        constexpr bool HASR = decltype(res_c)::value != 0, MAPC = decltype(map_c)::value != 0;
+        constexpr int NIT = 32 / RPI;  // store instructions per 32-row slab
+        const bool colok = n < g.N;     // N % 4 == 0 in this path, so a float4 is all-in or all-out
+        const int nc = colok ? n : 0;
 #pragma unroll
-        for (int it = 0; it < 32 / RPI; ++it) {
-          const int r = it * RPI + r0;
-          const int m = m0 + wm + i * 32 + r;
-          if (m < row_end) {
-            f32x4 v = *reinterpret_cast<const f32x4 *>(ep + r * TW + c4);
+        for (int i = 0; i < WM; i++) {
+          // residual rows first (clamped, unconditional: their latency hides under the transpose), then the
+          // transpose through LDS, then all row reads, and only the stores are predicated
+          f32x4 rv[NIT];
+          if constexpr (HASR) {
 #pragma unroll
-            for (int t = 0; t < 4; t++) v[t] = apply_act(v[t] + bv[t], g.act);
-            if (g.R) v += *reinterpret_cast<const f32x4 *>(g.R + (size_t)m * g.ldr + n);
-            const size_t crow = g.c_seg ? (size_t)(m / g.c_seg) * g.c_seg_stride + (m % g.c_seg) : (size_t)m;
-            *reinterpret_cast<f32x4 *>(g.C + crow * g.ldc + n) = v;
+            for (int it = 0; it < NIT; ++it) {
+              const int m = min(em0 + wm + i * 32 + it * RPI + r0, row_end - 1);
+              rv[it] = *reinterpret_cast<const f32x4 *>(g.R + (size_t)m * g.ldr + nc);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < WN; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) ep[((e & 3) + 8 * (e >> 2) + 4 * lhalf) * TW + j * 32 + lrow] = acc[i][j][e];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          constexpr int EB = NIT < 4 ? NIT : 4;  // rows in flight between the LDS read and the store
+#pragma unroll
+          for (int b = 0; b < NIT; b += EB) {
+            f32x4 cv[EB];
+#pragma unroll
+            for (int q = 0; q < EB; ++q) cv[q] = *reinterpret_cast<const f32x4 *>(ep + ((b + q) * RPI + r0) * TW + c4);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < EB; ++q) {
+              const int it = b + q;
+              const int m = em0 + wm + i * 32 + it * RPI + r0;
+              f32x4 v = cv[q];
+#pragma unroll
+              for (int t = 0; t < 4; t++) v[t] = apply_act_c<ACT>(v[t] + bv[t]);
+              if constexpr (HASR) v += rv[it];
+              size_t crow = (size_t)m;
+              if constexpr (MAPC) crow = (size_t)(m / g.c_seg) * g.c_seg_stride + (m % g.c_seg);
+              if (colok && m < row_end) *reinterpret_cast<f32x4 *>(g.C + crow * g.ldc + n) = v;
+            }
+          }
+        }
+      };
+      auto run_act = [&](auto act_c) {
+        if (g.c_seg) {
+          if (g.R) run(act_c, IntC<1>{}, IntC<1>{});
+          else run(act_c, IntC<0>{}, IntC<1>{});
+        } else {
+          if (g.R) run(act_c, IntC<1>{}, IntC<0>{});
+          else run(act_c, IntC<0>{}, IntC<0>{});
+        }
+      };
+      switch (g.act) {
+        case ACT_GELU: run_act(IntC<ACT_GELU>{}); break;
+        case ACT_SILU: run_act(IntC<ACT_SILU>{}); break;
+        case ACT_TANH: run_act(IntC<ACT_TANH>{}); break;
+        case ACT_LRELU: run_act(IntC<ACT_LRELU>{}); break;
+        default: run_act(IntC<ACT_NONE>{}); break;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < WN; j++) {
+        const int n = en0 + wn + j * 32 + lrow;
+        if (n >= g.N) continue;
+        const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; i++) {
+#pragma unroll
+          for (int e = 0; e < 16; e++) {
+            const int m = em0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
+            if (m < row_end) {
+              float v = apply_act(acc[i][j][e] + bv, g.act);
+              if (g.R) v += g.R[(size_t)m * g.ldr + n];
+              const size_t crow = g.c_seg ? (size_t)(m / g.c_seg) * g.c_seg_stride + (m % g.c_seg) : (size_t)m;
+              g.C[crow * g.ldc + n] = v;
+            }
           }
         }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS reads done before the slice is overwritten
     }
-    return;
-  }
-#pragma unroll
-  for (int j = 0; j < WN; j++) {
-    const int n = n0 + wn + j * 32 + lrow;
-    if (n >= g.N) continue;
-    const float bv = g.bias ? g.bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < WM; i++) {
-#pragma unroll
-      for (int e = 0; e < 16; e++) {
-        const int m = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
-        if (m < row_end) {
-          float v = apply_act(acc[i][j][e] + bv, g.act);
-          if (g.R) v += g.R[(size_t)m * g.ldr + n];
-          const size_t crow = g.c_seg ? (size_t)(m / g.c_seg) * g.c_seg_stride + (m % g.c_seg) : (size_t)m;
-          g.C[crow * g.ldc + n] = v;
-        }
-      }
-    }
+    if (!more) break;
+    __syncthreads();  // every wave is done with its transpose slice before the staging buffers are refilled
   }
 }
 
-// MIXED: workgroups >= g.big_blocks compute 64x64 tiles of the rows [m_split, M) (same launch, same pipeline)
-template <int WM, int WN, bool KTAIL, int NBUF, bool MIXED>
+// MIXED: workgroups >= g.big_blocks compute 64x64 tiles of the rows [m_split, M) (same launch, same pipeline).
+// PERSIST: gridDim.x resident workgroups walk the 128x128 tiles, then (MIXED) the 64x64 tiles of the remaining rows.
+template <int WM, int WN, bool KTAIL, int NBUF, bool MIXED, bool PERSIST>
 __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_f32_kernel(GemmArgs g) {
   constexpr int TBM = 64 * WM, TBN = 64 * WN;
   constexpr int EP_FLOATS = 4 * 32 * 32 * WN;  // epilogue transpose slices of the 4 waves (32 rows at a time)
@@ -341,21 +420,31 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_f32_kernel(GemmAr
     g.C += bz * g.sC;
     if (g.R) g.R += bz * g.sR;
   }
-  if constexpr (MIXED) {
-    if ((int)blockIdx.x >= g.big_blocks) {
-      gemm_tile<1, 1, KTAIL, NBUF>(g, (int)blockIdx.x - g.big_blocks, g.m_split, g.M, smem);
-      return;
+  if constexpr (PERSIST) {
+    gemm_tile<WM, WN, KTAIL, NBUF, true>(g, (int)blockIdx.x, (int)gridDim.x, 0, g.m_split, smem);
+    if constexpr (MIXED) {
+      __syncthreads();
+      // dealt from the far end: the workgroups with one big tile fewer take the small tiles first
+      gemm_tile<1, 1, KTAIL, NBUF, true>(g, (int)(gridDim.x - 1 - blockIdx.x), (int)gridDim.x, g.m_split, g.M, smem);
     }
+  } else {
+    if constexpr (MIXED) {
+      if ((int)blockIdx.x >= g.big_blocks) {
+        gemm_tile<1, 1, KTAIL, NBUF, false>(g, (int)blockIdx.x - g.big_blocks, 0, g.m_split, g.M, smem);
+        return;
+      }
+    }
+    gemm_tile<WM, WN, KTAIL, NBUF, false>(g, (int)blockIdx.x, 0, 0, g.m_split, smem);
   }
-  gemm_tile<WM, WN, KTAIL, NBUF>(g, (int)blockIdx.x, 0, g.m_split, smem);
 }
 
 static int g_stagger = 0;
 static int g_tile_override = 0;
 // 0 = heuristic; 1 = 128x128 / 2 LDS buffers, 2 = 128x64 / 2 buffers, 3 = 128x128 / 1 buffer, 4 = 128x64 / 1 buffer,
-// 5..8 = 1..4 with the start-up stagger, 9 = mixed 128x128 + 64x64 tail (2 buffers), 10 = mixed, 1 buffer
+// 5..8 = 1..4 with the start-up stagger, 9 = mixed 128x128 + 64x64 tail (2 buffers), 10 = mixed, 1 buffer,
+// 11 = persistent 128x128 (2 buffers, 2 workgroups per CU walk all tiles), 12 = persistent mixed
 extern "C" int sgic_gemm_set_tile(int mode) {
-  if (mode < 0 || mode > 10) return SGIC_EINVAL;
+  if (mode < 0 || mode > 12) return SGIC_EINVAL;
   g_stagger = (mode >= 5 && mode <= 8);
   g_tile_override = g_stagger ? mode - 4 : mode;
   return SGIC_OK;
@@ -371,14 +460,15 @@ static int gemm_launch(GemmArgs g, int batch, hipStream_t st) {
     return nb / ceil(nb);
   };
   bool narrow = N <= 64 || eff(64) > eff(128) + 0.04;
-  bool single = false, mixed = false;
+  bool single = false, mixed = false, persist = false;
   if (g_tile_override) {
     narrow = (g_tile_override == 2 || g_tile_override == 4);
     single = (g_tile_override == 3 || g_tile_override == 4 || g_tile_override == 10);
-    mixed = g_tile_override >= 9;
+    mixed = g_tile_override == 9 || g_tile_override == 10 || g_tile_override == 12;
+    persist = g_tile_override >= 11 && batch == 1;
   }
   const bool ktail = (K % BK) != 0;
-  if (ktail) single = mixed = false;
+  if (ktail) single = mixed = persist = false;
   const int tn = narrow ? (N + 63) / 64 : (N + 127) / 128;
   g.m_split = M;
   g.big_blocks = tm128 * tn;
@@ -386,7 +476,8 @@ static int gemm_launch(GemmArgs g, int batch, hipStream_t st) {
   if (mixed && batch == 1 && !narrow) {
     // 128x128 tiles for as many m-tile rows as fill whole multiples of the 256 CUs; the remaining rows (less than
     // one CU-round of work) go to 64x64 tiles, whose finer granularity ends the launch evenly
-    const int full = ((M / 128) * tn / 256) * 256;            // big tiles in whole CU-rounds
+    const int round = persist ? 512 : 256;                    // resident workgroups (persistent) / CUs
+    const int full = ((M / 128) * tn / round) * round;        // big tiles in whole rounds
     const int big_rows = (full / tn) * 128;
     if (big_rows <= 0 || big_rows >= M) {
       mixed = false;
@@ -398,7 +489,8 @@ static int gemm_launch(GemmArgs g, int batch, hipStream_t st) {
   } else {
     mixed = false;
   }
-  const dim3 grid(g.big_blocks + small_blocks, batch);
+  dim3 grid(g.big_blocks + small_blocks, batch);
+  if (persist) grid.x = min((int)grid.x, 2 * 256);  // 2 resident workgroups per CU (LDS-bound), 256 CUs
   {
     const int per_cu = single ? (narrow ? 4 : 3) : 2;
     const long total = (long)g.big_blocks * batch;
@@ -406,18 +498,23 @@ static int gemm_launch(GemmArgs g, int batch, hipStream_t st) {
     // one tile's MFMA time alone on a CU ~ nk * 64(32 narrow) MFMAs * 64 cycles; delay resident slot s by s/per_cu of it
     const long tile_cycles = (long)((K + BK - 1) / BK) * (narrow ? 32 : 64) * 64;
     g.stagger_cycles = (g_stagger && !mixed && total >= 2L * per_cu * 256) ? (int)(tile_cycles / per_cu) : 0;
+    static const char *fx = getenv("SGIC_GEMM_STAGGER_CYCLES");
+    if (fx && g.stagger_cycles) g.stagger_cycles = atoi(fx);
   }
-  if (mixed) {
-    if (single) gemm_f32_kernel<2, 2, false, 1, true><<<grid, 256, 0, st>>>(g);
-    else gemm_f32_kernel<2, 2, false, 2, true><<<grid, 256, 0, st>>>(g);
+  if (persist) {
+    if (mixed) gemm_f32_kernel<2, 2, false, 2, true, true><<<grid, 256, 0, st>>>(g);
+    else gemm_f32_kernel<2, 2, false, 2, false, true><<<grid, 256, 0, st>>>(g);
+  } else if (mixed) {
+    if (single) gemm_f32_kernel<2, 2, false, 1, true, false><<<grid, 256, 0, st>>>(g);
+    else gemm_f32_kernel<2, 2, false, 2, true, false><<<grid, 256, 0, st>>>(g);
   } else if (narrow) {
-    if (ktail) gemm_f32_kernel<2, 1, true, 2, false><<<grid, 256, 0, st>>>(g);
-    else if (single) gemm_f32_kernel<2, 1, false, 1, false><<<grid, 256, 0, st>>>(g);
-    else gemm_f32_kernel<2, 1, false, 2, false><<<grid, 256, 0, st>>>(g);
+    if (ktail) gemm_f32_kernel<2, 1, true, 2, false, false><<<grid, 256, 0, st>>>(g);
+    else if (single) gemm_f32_kernel<2, 1, false, 1, false, false><<<grid, 256, 0, st>>>(g);
+    else gemm_f32_kernel<2, 1, false, 2, false, false><<<grid, 256, 0, st>>>(g);
   } else {
-    if (ktail) gemm_f32_kernel<2, 2, true, 2, false><<<grid, 256, 0, st>>>(g);
-    else if (single) gemm_f32_kernel<2, 2, false, 1, false><<<grid, 256, 0, st>>>(g);
-    else gemm_f32_kernel<2, 2, false, 2, false><<<grid, 256, 0, st>>>(g);
+    if (ktail) gemm_f32_kernel<2, 2, true, 2, false, false><<<grid, 256, 0, st>>>(g);
+    else if (single) gemm_f32_kernel<2, 2, false, 1, false, false><<<grid, 256, 0, st>>>(g);
+    else gemm_f32_kernel<2, 2, false, 2, false, false><<<grid, 256, 0, st>>>(g);
   }
   return sgic::check_launch("gemm_f32_kernel");
 }

@@ -36,7 +36,7 @@ def empty(*shape, like=None, dtype=torch.float32, device=None):
 # give bitwise identical results (the k order is fixed), so tuning never changes an output.  AUTOTUNE = False uses
 # the built-in heuristic.  Single-threaded by design: one process per GPU, one launching thread.
 AUTOTUNE = True
-TUNE_MODES = (1, 2, 3, 4, 5, 7, 9, 10)   # {128x128, 128x64} x {double, single LDS buffer}, staggered wide, mixed 128x128 + 64x64 tail
+TUNE_MODES = (1, 2, 3, 4, 5, 7, 9, 10, 11, 12)   # {128x128, 128x64} x {double, single LDS buffer}, staggered wide, mixed 128x128 + 64x64 tail, persistent (plain, mixed)
 _TILE = {}
 
 
