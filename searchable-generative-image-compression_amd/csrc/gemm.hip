@@ -407,7 +407,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, int bid, int step, 
 // MIXED: workgroups >= g.big_blocks compute 64x64 tiles of the rows [m_split, M) (same launch, same pipeline).
 // PERSIST: gridDim.x resident workgroups walk the 128x128 tiles, then (MIXED) the 64x64 tiles of the remaining rows.
 template <int WM, int WN, bool KTAIL, int NBUF, bool MIXED, bool PERSIST>
-__global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_f32_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, (WM == 1 && WN == 1) ? 4 : (NBUF == 1 ? 3 : 2)) void gemm_f32_kernel(GemmArgs g) {
   constexpr int TBM = 64 * WM, TBN = 64 * WN;
   constexpr int EP_FLOATS = 4 * 32 * 32 * WN;  // epilogue transpose slices of the 4 waves (32 rows at a time)
   constexpr int ST_FLOATS = NBUF * (TBM + TBN) * LDS_LD;
@@ -442,9 +442,10 @@ static int g_stagger = 0;
 static int g_tile_override = 0;
 // 0 = heuristic; 1 = 128x128 / 2 LDS buffers, 2 = 128x64 / 2 buffers, 3 = 128x128 / 1 buffer, 4 = 128x64 / 1 buffer,
 // 5..8 = 1..4 with the start-up stagger, 9 = mixed 128x128 + 64x64 tail (2 buffers), 10 = mixed, 1 buffer,
-// 11 = persistent 128x128 (2 buffers, 2 workgroups per CU walk all tiles), 12 = persistent mixed
+// 11 = persistent 128x128 (2 buffers, 2 workgroups per CU walk all tiles), 12 = persistent mixed,
+// 13 / 14 = 64x64 tiles as their own launch (2 / 1 buffers, 4+ workgroups per CU): small-M GEMMs (CLIP tower, bottleneck)
 extern "C" int sgic_gemm_set_tile(int mode) {
-  if (mode < 0 || mode > 12) return SGIC_EINVAL;
+  if (mode < 0 || mode > 14) return SGIC_EINVAL;
   g_stagger = (mode >= 5 && mode <= 8);
   g_tile_override = g_stagger ? mode - 4 : mode;
   return SGIC_OK;
@@ -460,15 +461,16 @@ static int gemm_launch(GemmArgs g, int batch, hipStream_t st) {
     return nb / ceil(nb);
   };
   bool narrow = N <= 64 || eff(64) > eff(128) + 0.04;
-  bool single = false, mixed = false, persist = false;
+  bool single = false, mixed = false, persist = false, tiny = false;
   if (g_tile_override) {
     narrow = (g_tile_override == 2 || g_tile_override == 4);
-    single = (g_tile_override == 3 || g_tile_override == 4 || g_tile_override == 10);
+    single = (g_tile_override == 3 || g_tile_override == 4 || g_tile_override == 10 || g_tile_override == 14);
     mixed = g_tile_override == 9 || g_tile_override == 10 || g_tile_override == 12;
-    persist = g_tile_override >= 11 && batch == 1;
+    persist = (g_tile_override == 11 || g_tile_override == 12) && batch == 1;
+    tiny = g_tile_override >= 13;
   }
   const bool ktail = (K % BK) != 0;
-  if (ktail) single = mixed = persist = false;
+  if (ktail) single = mixed = persist = tiny = false;
   const int tn = narrow ? (N + 63) / 64 : (N + 127) / 128;
   g.m_split = M;
   g.big_blocks = tm128 * tn;
@@ -501,7 +503,13 @@ static int gemm_launch(GemmArgs g, int batch, hipStream_t st) {
     static const char *fx = getenv("SGIC_GEMM_STAGGER_CYCLES");
     if (fx && g.stagger_cycles) g.stagger_cycles = atoi(fx);
   }
-  if (persist) {
+  if (tiny) {
+    grid.x = ((M + 63) / 64) * ((N + 63) / 64);
+    g.big_blocks = (int)grid.x;
+    g.stagger_cycles = 0;
+    if (single) gemm_f32_kernel<1, 1, false, 1, false, false><<<grid, 256, 0, st>>>(g);
+    else gemm_f32_kernel<1, 1, false, 2, false, false><<<grid, 256, 0, st>>>(g);
+  } else if (persist) {
     if (mixed) gemm_f32_kernel<2, 2, false, 2, true, true><<<grid, 256, 0, st>>>(g);
     else gemm_f32_kernel<2, 2, false, 2, false, true><<<grid, 256, 0, st>>>(g);
   } else if (mixed) {

@@ -20,7 +20,7 @@ for (M, N, K, res, act) in [(9248, 1024, 1024, True, 0), (9248, 4096, 1024, Fals
     b = torch.rand(N, device=dev)
     r = torch.rand(M, N, device=dev) if res else None
     outs = {}
-    for mode in (1, 2, 3, 4, 5, 7, 9, 10, 11, 12):
+    for mode in (1, 2, 3, 4, 5, 7, 9, 10, 11, 12, 13, 14):
         lib.sgic_gemm_set_tile(mode)
         outs[mode] = ops.gemm(a, w, b, act=act, residual=r).clone()
     lib.sgic_gemm_set_tile(0)
