@@ -500,8 +500,6 @@ static int gemm_launch(GemmArgs g, int batch, hipStream_t st) {
     // one tile's MFMA time alone on a CU ~ nk * 64(32 narrow) MFMAs * 64 cycles; delay resident slot s by s/per_cu of it
     const long tile_cycles = (long)((K + BK - 1) / BK) * (narrow ? 32 : 64) * 64;
     g.stagger_cycles = (g_stagger && !mixed && total >= 2L * per_cu * 256) ? (int)(tile_cycles / per_cu) : 0;
-    static const char *fx = getenv("SGIC_GEMM_STAGGER_CYCLES");
-    if (fx && g.stagger_cycles) g.stagger_cycles = atoi(fx);
   }
   if (tiny) {
     grid.x = ((M + 63) / 64) * ((N + 63) / 64);
@@ -570,6 +568,52 @@ extern "C" int sgic_gemm_batched_f32(const float *d_A, int lda, long strideA, co
   return gemm_launch(g, batch, to_stream(stream));
 }
 
+// Thin-output 3x3 convolution (Cout <= 4, Cin == 128: the taming decoder's conv_out 128 -> 3, model.py:531-537).
+// A 64-column MFMA tile would spend 95 % of its work on padding, so this one is a VALU kernel bound by reading the
+// input once: 32 lanes share one pixel (lane = 4 channels, coalesced 512-byte rows per tap), each lane keeps its
+// 9 x COUT weight float4s in registers, partial dot products are combined by a fixed xor-shuffle tree.
+template <int COUT>
+__global__ __launch_bounds__(256) void conv3x3_thin_kernel(const float *__restrict__ in, const float *__restrict__ W,
+                                                           const float *__restrict__ bias, float *__restrict__ out, int ldc,
+                                                           long npix, int H, int Wd, int act) {
+  constexpr int CIN = 128;
+  const int l32 = threadIdx.x & 31;
+  const long group = ((long)blockIdx.x * 256 + threadIdx.x) >> 5, ngroups = (long)gridDim.x * 8;
+  f32x4 wr[COUT][9];
+#pragma unroll
+  for (int co = 0; co < COUT; co++)
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++) wr[co][tap] = *reinterpret_cast<const f32x4 *>(W + ((size_t)co * 9 + tap) * CIN + l32 * 4);
+  const int hw = H * Wd;
+  for (long pix = group; pix < npix; pix += ngroups) {
+    const int b = (int)(pix / hw), r = (int)(pix - (long)b * hw), y = r / Wd, x = r - y * Wd;
+    const float *base = in + (((size_t)b * (H + 2) + y) * (Wd + 2) + x) * CIN + l32 * 4;
+    f32x4 v[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++) v[tap] = *reinterpret_cast<const f32x4 *>(base + (size_t)((tap / 3) * (Wd + 2) + tap % 3) * CIN);
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; co++) {
+      float a = 0.f;
+#pragma unroll
+      for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) a = fmaf(v[tap][t], wr[co][tap][t], a);
+      acc[co] = a;
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+      for (int co = 0; co < COUT; co++) acc[co] += __shfl_xor(acc[co], o);
+    if (l32 < COUT) {
+      float r0 = acc[0];
+#pragma unroll
+      for (int co = 1; co < COUT; co++) r0 = (l32 == co) ? acc[co] : r0;
+      out[(size_t)pix * ldc + l32] = apply_act(r0 + (bias ? bias[l32] : 0.f), act);
+    }
+  }
+}
+
 // 3x3 stride-1 pad-1 convolution as an implicit GEMM over a zero-halo NHWC input [B, H+2, W+2, Cin]:
 // out[(b,y,x), n] = act(sum_{ky,kx,c} in[b, y+ky, x+kx, c] * W[n, (ky*3+kx)*Cin + c] + bias[n]) + R
 extern "C" int sgic_conv3x3_f32(const float *d_in_halo, const float *d_W, const float *d_bias, const float *d_R, int ldr,
@@ -581,6 +625,11 @@ extern "C" int sgic_conv3x3_f32(const float *d_in_halo, const float *d_W, const 
   int rc = gemm_check(d_in_halo, Cin, d_W, K, d_bias, d_R, ldr, d_out, ldc, M, Cout, K, act);
   if (rc) return rc;
   SGIC_REQUIRE(Cin % BK == 0, "implicit-GEMM conv needs Cin % 32 == 0");
+  if (Cout == 3 && Cin == 128 && !d_R) {
+    const unsigned grid = (unsigned)min((Ml + 7) / 8, 256L * 32);
+    conv3x3_thin_kernel<3><<<grid, 256, 0, to_stream(stream)>>>(d_in_halo, d_W, d_bias, d_out, ldc, Ml, H, W, act);
+    return sgic::check_launch("conv3x3_thin_kernel");
+  }
   GemmArgs g{d_in_halo, d_W, d_bias, d_R, d_out, M, Cout, K, Cin, K, ldr, ldc, act, 0, 0, 0, 0,
              vec_ok(d_bias, d_R, ldr, d_out, ldc, Cout, 0, 0), 0, 0, 0, 0, Cin, H, W, 0, 0, 0, 0};
   return gemm_launch(g, 1, to_stream(stream));

@@ -104,7 +104,7 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if tile:
-            lib.sgic_gemm_set_tile(tile)
+        lib.sgic_gemm_set_tile(tile)
     launch()
     if tile:
         lib.sgic_gemm_set_tile(0)
@@ -329,11 +329,17 @@ def conv3x3(x_halo, w, bias, B, H, W, Cin, Cout, residual=None, act=ACT_NONE, ou
         tile = _TILE.get(key)
         if tile is None:
             tile = _tune(key, launch)     # conv outputs never alias their residual: re-running is idempotent
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     if tile:
-            lib.sgic_gemm_set_tile(tile)
+        lib.sgic_gemm_set_tile(tile)
     launch()
     if tile:
         lib.sgic_gemm_set_tile(0)
+    if PROFILE is not None:   # the implicit-GEMM convolution is the same kernel: M = B*H*W, N = Cout, K = 9*Cin
+        e1.record()
+        PROFILE.append((2.0 * B * H * W * Cout * 9 * Cin, e0, e1, (B * H * W, Cout, 9 * Cin, residual is not None, act)))
     return out
 
 

@@ -118,3 +118,32 @@ def test_full_roundtrip_compress_decompress(codec):
     one = codec.decode_only(**{k: v for k, v in back[1].items()})
     assert torch.equal(one[0], x1[1])   # batch-invariant: B=1 decode == row of the B=2 decode
     assert torch.isfinite(x1).all()
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,res", [(2, 24, 40, 128, 3, False),      # thin VALU kernel (taming conv_out 128 -> 3)
+                                                  (2, 24, 40, 64, 128, True),      # implicit-GEMM path with residual
+                                                  (1, 16, 16, 128, 4, False)])     # Cout = 4 stays on the GEMM path
+def test_conv3x3_vs_torch(B, H, W, Cin, Cout, res):
+    """sgic_conv3x3_f32 (taming Conv2d 3x3 stride 1 pad 1, model.py:38-137,531-537) vs F.conv2d in fp64.
+    Tolerance: 2e-5 * max|ref| (fp32 accumulation over K = 9*Cin <= 1152 terms)."""
+    import sgic_amd  # noqa
+    from sgic_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(B, Cout, H, W, generator=g) if res else None
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if res:
+        ref = ref + r.double()
+    halo = torch.zeros(B, H + 2, W + 2, Cin, device="cuda:0")
+    halo[:, 1:-1, 1:-1] = x.permute(0, 2, 3, 1).cuda()
+    wk = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().cuda()            # (ky, kx, cin) order
+    ld = 4 if Cout == 3 else Cout
+    out = torch.zeros(B * H * W, ld, device="cuda:0")
+    rr = r.permute(0, 2, 3, 1).reshape(B * H * W, Cout).contiguous().cuda() if res else None
+    ops.conv3x3(halo, wk, b.cuda(), B, H, W, Cin, Cout, residual=rr, out=out[:, :Cout])
+    got = out[:, :Cout].reshape(B, H, W, Cout).permute(0, 3, 1, 2).cpu().double()
+    assert float((got - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    if ld > Cout:
+        assert float(out[:, Cout:].abs().max()) == 0.0      # the padding column of the output buffer is untouched
