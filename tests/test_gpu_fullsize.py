@@ -84,3 +84,81 @@ def test_config5_512_compress_and_decompress(large):
     assert x_hat.shape == (B, 3, 512, 512) and bool(torch.isfinite(x_hat).all())
     one = codec.decode_batch([encs[2]])
     assert torch.equal(one[0], x_hat[2])
+
+
+def test_large_architecture_vs_torch_oracle(large):
+    """Numeric parity at the PRODUCTION architecture (24-layer ViT-L hybrid encoder, bottleneck, 4-step prior):
+    the HIP path vs oracle/torch_ref.py on the CPU, one 256x256 image (the oracle itself is pinned against the real
+    reference modules at the SMALL width, tests/test_oracle_nn.py).  Tolerances: z, h, y within 2e-4 * max|ref|;
+    VQ indices identical; symbols / indexes of the 4-step quantiser run on the ORACLE's y identical up to 0.5 %
+    (bin-edge ulp flips), and the resulting stream equals the C oracle's coding of the same symbols."""
+    from oracle import torch_ref as TR
+    from sgic_amd import ops
+    from sgic_amd.config import LARGE
+    from sgic_amd.data import synth_images
+    codec, cfg, sd = large, LARGE, large._sd
+    x = synth_images(1, 256, 256, seed=31)
+    r = codec.encode_device(x.cuda())
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    with torch.no_grad():
+        z_ref, h_ref, _ = TR.encoder_forward(x * 0.5 + 0.5, sd, cfg)
+        vq_ref = TR.vq_indices(z_ref, sd).numpy().reshape(-1)
+        y_ref = TR.bottleneck_analysis(h_ref, sd)
+        s_ref, i_ref, _, _ = TR.four_part_prior_write(y_ref, sd, cfg.force_zero_thres)
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    T, C = cfg.num_latent_tokens, cfg.token_size
+    ez = rel(r["z"].cpu().reshape(1, T, C).permute(0, 2, 1).reshape(1, C, 1, T), z_ref)
+    eh = rel(r["h"].cpu().reshape(1, 8, 8, -1).permute(0, 3, 1, 2), h_ref)
+    b = codec.bottleneck
+    y = b.analysis(r["h"], 1, 8, 8)
+    ey = rel(y.cpu().reshape(1, 8, 8, -1).permute(0, 3, 1, 2), y_ref)
+    print(f"LARGE vs torch oracle: rel err z {ez:.2e} h {eh:.2e} y {ey:.2e}")
+    assert ez < 2e-4 and eh < 2e-4 and ey < 2e-4
+    assert np.array_equal(r["vq"].cpu().numpy().reshape(-1), vq_ref)
+    yr = y_ref.permute(0, 2, 3, 1).reshape(64, -1).contiguous().cuda()
+    sym, idx, _, _ = b.quantise(yr, 1, 8, 8)
+    s_m = float((sym.cpu().numpy().reshape(-1) != s_ref.numpy().reshape(-1)).mean())
+    i_m = float((idx.cpu().numpy().reshape(-1) != i_ref.numpy().reshape(-1)).mean())
+    print(f"   4-step mismatch rate on the oracle's y: symbols {s_m:.5f} indexes {i_m:.5f}")
+    assert s_m <= 0.005 and i_m <= 0.005
+    out, meta = ops.rans_encode_batch(b.tables.handles[b.group], sym, idx, 1, sym[0].numel())
+    stream = b.streams_to_host(out, meta)[0]
+    assert stream == orc.rans_encode(sym[0].cpu().numpy().reshape(-1), idx[0].cpu().numpy().reshape(-1), orc.Table(*b.cdf_info))
+
+
+def test_large_architecture_decode_vs_torch_oracle(large):
+    """Decode side at the production architecture: GPU decode_batch of one image's streams vs the torch oracle run
+    on the same entropy-decoded symbols (prior chain -> synthesis -> 24-layer hybrid decoder -> FeatMerge -> soft
+    codebook lookup -> taming VQGAN decoder).  Tolerances: y_hat-derived h_hat, titok, feat, latent within
+    5e-4 * max|ref| (as tests/test_gpu_decoder.py), pixels PSNR > 80 dB against the oracle's reconstruction."""
+    from oracle import torch_ref as TR
+    from sgic_amd.config import LARGE
+    from sgic_amd.data import synth_images
+    codec, cfg, sd = large, LARGE, large._sd
+    x = synth_images(1, 256, 256, seed=32).cuda()
+    r = codec.encode_device(x)
+    enc = codec.encode_batch(x)
+    taps = {}
+    x_hat = codec.decode_batch(enc, taps=taps).cpu()
+    sym = r["sym"].cpu().reshape(1, 4, 16, 8, 8)
+    idx = r["idx"].cpu().reshape(1, 4, 16, 8, 8)
+    sym = torch.where(idx < 0, torch.zeros_like(sym), sym)        # what the entropy decoder returns for skipped positions
+    with torch.no_grad():
+        y_hat, idx_ref = TR.four_part_prior_decode(sym, sd, cfg.force_zero_thres, 1, 8, 8)
+        assert torch.equal(idx_ref.reshape(-1), idx.reshape(-1).to(idx_ref.dtype))     # decoder re-derives the encoder's indexes
+        h_ref = TR.bottleneck_synthesis(y_hat, sd)
+        z_ref = TR.z_from_indices(r["vq"].cpu().reshape(-1), 1, sd, cfg)
+        t_ref, f_ref = TR.decoder_forward(z_ref, h_ref, (1, 1), sd, cfg)
+        logits = TR.featmerge_forward(t_ref, f_ref, sd, cfg)
+        lat_ref = TR.soft_lookup(logits, sd)
+        x_ref = TR.vqgan_decode(lat_ref, sd, cfg).clamp(-1, 1)
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    nchw = lambda t: t.cpu().reshape(1, 1, 1, 16, 16, t.shape[1]).permute(0, 5, 1, 3, 2, 4).reshape(1, t.shape[1], 16, 16)
+    e = dict(h_hat=rel(taps["h_hat"].cpu().reshape(1, 8, 8, -1).permute(0, 3, 1, 2), h_ref), titok=rel(nchw(taps["titok"]), t_ref),
+             feat=rel(nchw(taps["feat"]), f_ref), latent=rel(nchw(taps["latent"]), lat_ref))
+    mse = float(((x_hat - x_ref) ** 2).mean())
+    psnr = 10 * np.log10(4.0 / max(mse, 1e-20))
+    print(f"LARGE decode vs torch oracle: rel err {{{', '.join(f'{k} {v:.1e}' for k, v in e.items())}}} "
+          f"max|dx| {float((x_hat - x_ref).abs().max()):.1e} PSNR {psnr:.1f} dB")
+    assert all(v < 5e-4 for v in e.values()), e
+    assert psnr > 80.0
