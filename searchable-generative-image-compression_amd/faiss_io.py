@@ -39,7 +39,8 @@ class FaissDB:
         os.makedirs(index_dir, exist_ok=True)
         self.index_path = os.path.join(index_dir, "index.faiss")
         self.ids_path = os.path.join(index_dir, "ids.txt")
-        self.vecs = read_index_flat_ip(self.index_path) if os.path.exists(self.index_path) else np.zeros((0, dim), np.float32)
+        self._base = read_index_flat_ip(self.index_path) if os.path.exists(self.index_path) else np.zeros((0, dim), np.float32)
+        self._new = []          # rows appended since the last merge (a 10 k corpus must not re-copy the matrix per add)
         self.ids = []
         if os.path.exists(self.ids_path):
             with open(self.ids_path, "r", encoding="utf-8") as f:
@@ -48,8 +49,15 @@ class FaissDB:
     def add(self, vec_unit, doc_id):
         v = np.asarray(vec_unit, dtype=np.float32).copy()[None, :]
         v /= np.linalg.norm(v, axis=1, keepdims=True) + 1e-12
-        self.vecs = np.concatenate([self.vecs, v.astype(np.float32)], axis=0)
+        self._new.append(v.astype(np.float32))
         self.ids.append(doc_id)
+
+    @property
+    def vecs(self):
+        if self._new:
+            self._base = np.concatenate([self._base] + self._new, axis=0)
+            self._new = []
+        return self._base
 
     def persist(self):
         write_index_flat_ip(self.index_path, self.vecs)

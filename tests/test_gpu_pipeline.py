@@ -53,3 +53,33 @@ def test_compress_search_decompress_cli(tmp_path):
     for i, (h, w) in enumerate(sizes):
         im = Image.open(out / "results" / f"im{i:02d}.png")
         assert im.size == (w, h)
+
+
+def test_search_topk_parity_10k_corpus(tmp_path):
+    """BASELINE.json configs[3] at its size: a 10 000 x 512 IndexFlatIP (written in the FAISS on-disk layout and read
+    back), 16 queries, top-10: GPU GEMM + top-k kernel vs numpy exact search (search.py:113-120).  Indices must be
+    identical (ties -> lower index, as IndexFlatIP); scores within 1e-5 (fp32 dot products of unit vectors)."""
+    import sgic_amd  # noqa
+    from sgic_amd import search
+    from sgic_amd.faiss_io import FaissDB, read_index_flat_ip
+    rng = np.random.default_rng(7)
+    db = rng.standard_normal((10000, 512), dtype=np.float32)
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    db[4321] = db[1234]                      # an exact duplicate: a tie that must resolve to the lower index
+    fdb = FaissDB(str(tmp_path), 512)
+    for i in range(db.shape[0]):
+        fdb.add(db[i], f"bitstreams/im{i:05d}.c2df")
+    fdb.persist()
+    vecs, paths = search.load_index(tmp_path)
+    assert vecs.shape == (10000, 512) and len(paths) == 10000 and np.array_equal(vecs, read_index_flat_ip(str(tmp_path / "index.faiss")))
+    q = np.concatenate([vecs[[1234, 17, 9999]], rng.standard_normal((13, 512), dtype=np.float32)])
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    s, i = search.search_gpu(q, vecs, 10)
+    full = q.astype(np.float64) @ vecs.astype(np.float64).T
+    ref = np.argsort(-full, axis=1, kind="stable")[:, :10]
+    assert i[0, 0] == 1234 and i[0, 1] == 4321 and i[1, 0] == 17 and i[2, 0] == 9999
+    # fp32 rounding can swap neighbours whose fp64 scores differ by < 1e-6; everywhere else the order is exact
+    for r in range(q.shape[0]):
+        if not np.array_equal(i[r], ref[r]):
+            assert set(i[r]) == set(ref[r]) or np.abs(np.sort(full[r, i[r]])[::-1] - np.sort(full[r, ref[r]])[::-1]).max() < 1e-6, r
+        assert np.allclose(s[r], full[r, i[r]], atol=1e-5)
