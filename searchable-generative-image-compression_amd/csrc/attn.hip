@@ -116,7 +116,11 @@ __global__ __launch_bounds__(640) void attn_f32_kernel(AttnArgs a) {
     }
   };
 
-  const int ntiles = (a.L + AT_KT - 1) / AT_KT;
+  // Ragged tail: L = 289 and 545 are 9 / 17 full key tiles plus ONE key.  A 32-key MFMA tile for one key is
+  // 97 % padding, so a tail of <= 2 keys is folded into the online softmax on the VALU instead (a rank-1 update).
+  const int rem = a.L % AT_KT;
+  const bool tail_valu = rem > 0 && rem <= 2;
+  const int ntiles = tail_valu ? a.L / AT_KT : (a.L + AT_KT - 1) / AT_KT;
   issue_stage(0);
   for (int kt = 0; kt < ntiles; ++kt) {
     const int key0 = kt * AT_KT;
@@ -177,6 +181,38 @@ __global__ __launch_bounds__(640) void attn_f32_kernel(AttnArgs a) {
       const float v0 = sV[key * AT_LDV + lq], v1 = sV[key * AT_LDV + 32 + lq];
       o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[e], o0, 0, 0, 0);
       o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[e], o1, 0, 0, 0);
+    }
+  }
+
+  if (tail_valu) {
+    for (int key = ntiles * AT_KT; key < a.L; ++key) {
+      const long row = a.rowmap ? a.rowmap[(long)seq * a.L + key] : (long)seq * a.L + key;
+      const float *kp = a.k + row * a.ldk + hc, *vp = a.v + row * a.ldv + hc;
+      float sc = 0.f;  // this lane's half of q . k (dims (2c+lh)*4 + t), completed by the cross-half shuffle
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const f32x4 k4 = *reinterpret_cast<const f32x4 *>(kp + (2 * c + lh) * 4);
+#pragma unroll
+        for (int t = 0; t < 4; t++) sc = fmaf(k4[t], qf[c * 4 + t], sc);
+      }
+      sc += __shfl_xor(sc, 32);
+      if (bias_base) sc += bias_base[key];
+      const float m_new = fmaxf(m_run, sc);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = __expf(m_run - m_use);
+      const float pk = __expf(sc - m_use);
+      l_run = l_run * alpha + (lh == 0 ? pk : 0.f);  // l_run is a per-half partial sum: count the key once
+      m_run = m_new;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4++) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(vp + 8 * g4 + 4 * lh);
+        const f32x4 v1 = *reinterpret_cast<const f32x4 *>(vp + 32 + 8 * g4 + 4 * lh);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          o0[g4 * 4 + t] = fmaf(pk, v0[t], o0[g4 * 4 + t] * alpha);
+          o1[g4 * 4 + t] = fmaf(pk, v1[t], o1[g4 * 4 + t] * alpha);
+        }
+      }
     }
   }
 
