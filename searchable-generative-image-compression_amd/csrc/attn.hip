@@ -55,6 +55,7 @@ __global__ __launch_bounds__(640) void attn_f32_kernel(AttnArgs a) {
   const int lq = lane & 31, lh = lane >> 5;
   const int q_tok = (qb * a.nwaves + wave) * 32 + lq;  // this lane's query token
   const bool q_ok = q_tok < a.L;
+  const bool wave_active = (qb * a.nwaves + wave) * 32 < a.L;
   const int q_tok_c = q_ok ? q_tok : a.L - 1;
   const long q_row = a.rowmap ? a.rowmap[(long)seq * a.L + q_tok_c] : (long)seq * a.L + q_tok_c;
   const int hc = head * 64;
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(640) void attn_f32_kernel(AttnArgs a) {
     store_stage();
     __syncthreads();
     if (kt + 1 < ntiles) issue_stage(key0 + AT_KT);  // next tile's loads fly during this tile's 64 MFMAs
+    if (!wave_active) continue;  // a wave whose 32 query rows are all padding only helps staging (wave-uniform)
 
     // ---- S^T[key][q] = sum_d K[key][d] * Q[q][d] ----
     f32x16 s;
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(640) void attn_f32_kernel(AttnArgs a) {
     }
   }
 
-  if (tail_valu) {
+  if (tail_valu && wave_active) {
     for (int key = ntiles * AT_KT; key < a.L; ++key) {
       const long row = a.rowmap ? a.rowmap[(long)seq * a.L + key] : (long)seq * a.L + key;
       const float *kp = a.k + row * a.ldk + hc, *vp = a.v + row * a.ldv + hc;
