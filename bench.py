@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--h2d", action="store_true", help="also copy the input batch host->device inside every step "
                     "(PCIe-inclusive rate for DESIGN.md; never the headline value)")
-    ap.add_argument("--cpu-images", type=int, default=6)
+    ap.add_argument("--cpu-images", type=int, default=32, help="CPU-baseline sample: images of the same workload, B=1 loop, cut off after 25 s")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
