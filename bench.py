@@ -112,18 +112,18 @@ def main():
     x = synth_images(B, S, S, seed=1000 + rank).to(dev)   # inputs resident in HBM before the timed region
     gathered = torch.empty(world * B, clip_cfg.embed_dim, device=dev) if world > 1 else None
 
-    # Two-deep software pipeline over steps: the GPU work of step i (encoder, entropy coding, CLIP, async D2H into
-    # pinned buffers) is enqueued before the host finishes step i-1 (slice the streams, zstd the CLIP codes), so
-    # the host-side byte work hides under the GPU.  Every step still ends as 32 x (z, h, clip) host byte strings
-    # inside the timed region.  The rANS kernel (serial, ~1 ms) runs on a side HIP stream under the CLIP tower.
-    side = torch.cuda.Stream(device=dev)
-    ntok = cfg.num_latent_tokens * (S // cfg.crop_size) ** 2
-    cap = 2 * (4 * (cfg.embed_dim // 4) * (S // 32) ** 2) + 64
-    from sgic_amd._lib import lib as _sl
-    pinned = [dict(hs=torch.empty(B, cap, dtype=torch.uint8).pin_memory(), meta=torch.empty(3, B, dtype=torch.int32).pin_memory(),
-                   zs=torch.empty(B, _sl.sgic_pack12_size(ntok), dtype=torch.uint8).pin_memory(),
-                   q=torch.empty(B, clip_cfg.embed_dim, dtype=torch.uint8).pin_memory()) for _ in range(2)]
+    # Two-deep software pipeline over steps (sgic_amd.pipeline.CompressPipeline, the same object compress.py drives):
+    # the GPU work of step i (encoder, entropy coding, CLIP, async D2H into pinned buffers) is enqueued before the
+    # host finishes step i-1 (slice the streams, zstd the CLIP codes), so the host-side byte work hides under the GPU.
+    # Every step still ends as 32 x (z, h, clip) host byte strings inside the timed region.  The rANS kernel (serial,
+    # ~1 ms) runs on a side HIP stream under the CLIP tower.
+    from sgic_amd.pipeline import CompressPipeline
 
+    def gather(unit):
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, unit)   # CLIP vectors for the FAISS index (RCCL over xGMI)
+
+    pipe = CompressPipeline(codec, clipc, dev, on_unit=gather)
     x_host = x.cpu().pin_memory() if args.h2d else None
 
     def enqueue(slot):
@@ -131,29 +131,10 @@ def main():
         if args.h2d:
             xin = torch.empty_like(x)
             xin.copy_(x_host, non_blocking=True)
-        r = codec.encode_device(xin, side_stream=side)
-        unit, q = clipc.batch_to_codes(xin)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, unit)   # CLIP vectors for the FAISS index (RCCL over xGMI)
-        torch.cuda.current_stream().wait_stream(side)
-        p = pinned[slot]
-        p["hs"].copy_(r["hs"], non_blocking=True)
-        p["meta"].copy_(r["hmeta"], non_blocking=True)
-        p["zs"].copy_(r["zs"], non_blocking=True)
-        p["q"].copy_(q, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        return p, ev, r
+        return pipe.submit(xin)
 
     def finalize(h):
-        p, ev, _ = h
-        ev.synchronize()
-        meta = p["meta"].numpy()
-        if int(np.abs(meta[2]).sum()) != 0:
-            raise RuntimeError(f"rANS encode error codes {meta[2].tolist()}")
-        hs, zs, qh = p["hs"].numpy(), p["zs"].numpy(), p["q"].numpy()
-        return [(zs[b].tobytes(), hs[b, meta[0, b]:meta[0, b] + meta[1, b]].tobytes(), clipc.compress_codes(qh[b]))
-                for b in range(B)]
+        return [(d["z_bit_stream"], d["h_bit_stream"], d["clip_stream"]) for d in pipe.finish(h)]
 
     class _Pipe:
         prev, i, last = None, 0, None

@@ -100,27 +100,41 @@ def main(argv=None):
     for i, (p, im) in enumerate(imgs):
         groups.setdefault(tuple(im.shape[1:]), []).append(i)
     vecs = np.zeros((len(mine), ccfg.embed_dim), dtype=np.float32)
+    from .pipeline import CompressPipeline
+    pipe = CompressPipeline(model, clipc, dev, want_unit=True)
+
+    def write_out(job):
+        """host side of one batch: .c2df container + clip vector per image (compress.py:268-291)"""
+        h, chunk, (H, Wd), pad = job
+        pl, pr, pt, pb = pad
+        for j, (i, streams) in enumerate(zip(chunk, pipe.finish(h))):
+            stem = os.path.splitext(os.path.basename(imgs[i][0]))[0]
+            enc = pipe.enc_result(h, j, streams)
+            enc["clip_stream"] = streams["clip_stream"]
+            enc["clip_meta"] = clipc.meta(ccfg.embed_dim)
+            header = {"version": 2, "model_id": enc["clip_meta"]["model_id"], "embed_dim": int(ccfg.embed_dim),
+                      "quant_type": "u8_symmetric_-1_1", "image_hw": [int(H), int(Wd)],
+                      "padding": [int(pl), int(pr), int(pt), int(pb)]}
+            with open(os.path.join(bit_dir, f"{stem}.c2df"), "wb") as f:
+                f.write(pack_c2df(enc, header))
+            np.save(os.path.join(clip_dir, f"{stem}.npy"), streams["clip_unit"])
+            vecs[i] = streams["clip_unit"]
+
+    # two-deep pipeline: the GPU works on batch k+1 while the host packs and writes batch k
+    pending = None
     for (H, Wd), idxs in groups.items():
-        pl, pr, pt, pb = get_padding_size(H, Wd, p=256)
+        pad = get_padding_size(H, Wd, p=256)
+        pl, pr, pt, pb = pad
         for s in range(0, len(idxs), args.batch_size):
             chunk = idxs[s:s + args.batch_size]
             x = torch.stack([imgs[i][1] for i in chunk]).to(dev)
             xp = torch.nn.functional.pad(x, (pl, pr, pt, pb), mode="replicate").contiguous()   # data movement only
-            encs = model.encode_batch(xp)
-            unit, q = clipc.batch_to_codes(x.contiguous())          # CLIP sees the UNPADDED image (compress.py:266)
-            unit_h, q_h = unit.cpu().numpy(), q.cpu().numpy()
-            for j, i in enumerate(chunk):
-                stem = os.path.splitext(os.path.basename(imgs[i][0]))[0]
-                enc = encs[j]
-                enc["clip_stream"] = clipc.compress_codes(q_h[j])
-                enc["clip_meta"] = clipc.meta(ccfg.embed_dim)
-                header = {"version": 2, "model_id": enc["clip_meta"]["model_id"], "embed_dim": int(ccfg.embed_dim),
-                          "quant_type": "u8_symmetric_-1_1", "image_hw": [int(H), int(Wd)],
-                          "padding": [int(pl), int(pr), int(pt), int(pb)]}
-                with open(os.path.join(bit_dir, f"{stem}.c2df"), "wb") as f:
-                    f.write(pack_c2df(enc, header))
-                np.save(os.path.join(clip_dir, f"{stem}.npy"), unit_h[j])
-                vecs[i] = unit_h[j]
+            h = pipe.submit(xp, clip_hw=(H, Wd))     # CLIP sees the UNPADDED top-left H x W region (compress.py:266)
+            if pending is not None:
+                write_out(pending)
+            pending = (h, chunk, (H, Wd), pad)
+    if pending is not None:
+        write_out(pending)
     allv = gather_vectors(torch.from_numpy(vecs).to(dev), len(files), rank, world).cpu().numpy()
     if rank == 0 and len(files) > 0:
         db = FaissDB(index_dir, ccfg.embed_dim)
