@@ -89,7 +89,7 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(
              a_seg[0], a_seg[1], c_seg[0], c_seg[1])
 
     tile = 0
-    if AUTOTUNE and M * N >= (1 << 20):
+    if AUTOTUNE and M * N >= (1 << 16):
         key = (M, N, K, residual is not None, act, str(a.device))
         tile = _TILE.get(key)
         if tile is None:
