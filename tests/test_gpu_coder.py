@@ -266,3 +266,32 @@ def test_error_paths_enospc_and_bad_index(tab):
     with pytest.raises(IndexError):
         enc.encode_with_indexes(sym[1], idx_bad[1], 0)
         enc.flush()
+
+
+def test_torchac_shim_vs_reference_sample_and_oracle(golden_dir):
+    """seam B2 (models/codec_sq_fixbpp.py:864,887): sgic_amd.torchac.{encode,decode}_float_cdf with the codec's uniform
+    cdf reproduce the z_bit_stream of the reference's own apple.c2df byte for byte, agree with the C restatement of
+    torchac's coder (oracle), round-trip, and refuse any other cdf."""
+    import sgic_amd  # noqa
+    import sgic_amd.torchac as torchac
+    from sgic_amd.filemaker import unpack_c2df
+    enc, _ = unpack_c2df(os.path.join(golden_dir, "ref_apple.c2df"))
+    z, n = enc["z_bit_stream"], int(enc["token_length"])
+    cdf = torch.zeros(4097)
+    cdf[1:] = torch.cumsum(torch.ones(4096) / 4096, dim=0)                 # Codec.set_torchac (:841-846)
+    shaped = cdf.unsqueeze(0).repeat(n, 1)
+    idx = torchac.decode_float_cdf(shaped, z)
+    assert idx.dtype == torch.int16 and idx.shape == (n,) and np.array_equal(idx.numpy(), orc.unpack12(z, n))
+    assert torchac.encode_float_cdf(shaped, idx) == z
+    rng = np.random.default_rng(5)
+    for m in (1, 2, 31, 32, 33, 128):
+        s = torch.from_numpy(rng.integers(0, 4096, size=m).astype(np.int16))
+        c = cdf.unsqueeze(0).repeat(m, 1)
+        b = torchac.encode_float_cdf(c, s)
+        assert b == orc.torchac_uniform_encode(s.numpy()) and torch.equal(torchac.decode_float_cdf(c, b), s)
+    with pytest.raises(NotImplementedError):
+        torchac.encode_float_cdf(torch.linspace(0, 1, 11).unsqueeze(0), torch.zeros(1, dtype=torch.int16))
+    with pytest.raises(NotImplementedError):
+        torchac.encode_float_cdf((cdf ** 2).unsqueeze(0), torch.zeros(1, dtype=torch.int16))
+    with pytest.raises(ValueError):
+        torchac.decode_float_cdf(shaped, z[:-1])
