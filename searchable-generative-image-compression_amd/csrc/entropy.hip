@@ -285,67 +285,99 @@ __global__ void rans_decode_init_kernel(const uint8_t *streams, int cap, const i
   state[b * 4 + 3] = 0;
 }
 
-__global__ void rans_decode_kernel(const int32_t *__restrict__ cdf, const int32_t *__restrict__ sizes,
-                                   const int32_t *__restrict__ offsets, int rows, int cols,
-                                   const uint8_t *__restrict__ streams, int cap, const int32_t *d_off,
-                                   const int32_t *d_len, int B, uint32_t *state, const int16_t *__restrict__ idx,
-                                   int n, int idx_stride, int16_t *__restrict__ out, int out_stride) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+// One workgroup (256 threads) per image.  The whole quantised-cdf table (rows x cols int32, 105 KB for the codec's
+// 256 x 103 table) and a window of the stream are staged in LDS; wave 0 then walks the symbols.  The recurrence is
+// serial, but the cdf search is not: lane j compares row[j] and row[j+64] with the 16-bit cumulative value and one
+// ballot + popcount gives the symbol (rows are strictly increasing), instead of 7 dependent binary-search probes.
+// Symbol indexes are fetched and results stored 64 at a time, coalesced.
+#define DEC_WIN 4096
+__global__ __launch_bounds__(256) void rans_decode_kernel(const int32_t *__restrict__ cdf, const int32_t *__restrict__ sizes,
+                                                          const int32_t *__restrict__ offsets, int rows, int cols,
+                                                          const uint8_t *__restrict__ streams, int cap, const int32_t *d_off,
+                                                          const int32_t *d_len, int B, uint32_t *state,
+                                                          const int16_t *__restrict__ idx, int n, int idx_stride,
+                                                          int16_t *__restrict__ out, int out_stride) {
+  extern __shared__ __attribute__((aligned(16))) int32_t s_dyn[];
+  int32_t *s_cdf = s_dyn;                                   // [rows * cols]
+  int32_t *s_size = s_dyn + rows * cols;                    // [rows]
+  int32_t *s_offs = s_size + rows;                          // [rows]
+  uint8_t *s_win = reinterpret_cast<uint8_t *>(s_offs + rows);   // [DEC_WIN] stream bytes from the cursor on
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int off = d_off ? d_off[b] : 0;
-  DecCursor c{streams + (size_t)b * cap + off, (int)state[b * 4 + 1], d_len[b], (int)state[b * 4 + 2]};
+  const uint8_t *sp = streams + (size_t)b * cap + off;
+  const int len = d_len[b], pos0 = (int)state[b * 4 + 1];
+  for (int i = tid; i < rows * cols; i += 256) s_cdf[i] = cdf[i];
+  for (int i = tid; i < rows; i += 256) s_size[i] = sizes[i], s_offs[i] = offsets[i];
+  for (int i = tid; i < DEC_WIN; i += 256) s_win[i] = (pos0 + i < len) ? sp[pos0 + i] : (uint8_t)0;
+  __syncthreads();
+  if (tid >= 64) return;
+
+  // every lane of wave 0 carries the same cursor (uniform control flow); only the cdf probe is lane-parallel
   uint32_t x = state[b * 4 + 0];
+  int pos = pos0, err = (int)state[b * 4 + 2];
+  auto next = [&]() -> uint32_t {
+    if (pos < len) {
+      const int w = pos - pos0;
+      const uint32_t v = (w < DEC_WIN) ? s_win[w] : sp[pos];
+      ++pos;
+      return v;
+    }
+    err = 1;  // the reference over-reads silently (rans.cpp:53-68); we flag it
+    return 0;
+  };
   idx += (size_t)b * idx_stride;
   out += (size_t)b * out_stride;
-  for (int i = 0; i < n; ++i) {
-    const int ci = idx[i];
-    if (ci < 0) {
-      out[i] = 0;
-      continue;
-    }
-    if (ci >= rows || c.err) {
-      c.err = c.err ? c.err : 3;
-      out[i] = 0;
-      continue;
-    }
-    const int32_t *row = cdf + (size_t)ci * cols;
-    const int size = sizes[ci], max_value = size - 2;
-    const uint32_t cum = x & 0xffffu;
-    // largest s with row[s] <= cum  (== find_if(row[v] > cum) - 1; rows are strictly increasing)
-    int lo = 0, hi = size - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if ((uint32_t)row[mid] <= cum)
-        lo = mid;
-      else
-        hi = mid - 1;
-    }
-    const uint32_t start = (uint32_t)row[lo], freq = (uint32_t)row[lo + 1] - start;
-    x = freq * (x >> 16) + cum - start;
-    while (x < RANS_L) x = (x << 8) | c.next();
-    int value = lo;
-    if (value == max_value) {
-      auto bits2 = [&]() {
-        uint32_t v = x & 3u;
-        x >>= 2;
-        if (x < RANS_L) x = (x << 8) | c.next();
-        return (int)v;
-      };
-      int val = bits2(), nb = val;
-      while (val == 3 && !c.err) {
-        val = bits2();
-        nb += val;
+  for (int base = 0; base < n; base += 64) {
+    const int cnt = min(64, n - base);
+    const int my_ci = (lane < cnt) ? (int)idx[base + lane] : -1;
+    int my_val = 0;
+    for (int k = 0; k < cnt; ++k) {
+      const int ci = __shfl(my_ci, k);
+      int value = 0;
+      if (ci >= 0) {
+        if (ci >= rows || err) {
+          err = err ? err : 3;
+        } else {
+          const int32_t *row = s_cdf + ci * cols;
+          const int size = s_size[ci], max_value = size - 2;
+          const uint32_t cum = x & 0xffffu;
+          // number of j with row[j] <= cum  ==  (largest such j) + 1 ; row[0] = 0 so it is >= 1
+          const bool p0 = lane < size && (uint32_t)row[lane] <= cum;
+          const bool p1 = lane + 64 < size && (uint32_t)row[lane + 64] <= cum;
+          const int lo = __popcll(__ballot(p0)) + __popcll(__ballot(p1)) - 1;
+          const uint32_t start = (uint32_t)row[lo], freq = (uint32_t)row[lo + 1] - start;
+          x = freq * (x >> 16) + cum - start;
+          while (x < RANS_L) x = (x << 8) | next();
+          value = lo;
+          if (value == max_value) {
+            auto bits2 = [&]() {
+              uint32_t v = x & 3u;
+              x >>= 2;
+              if (x < RANS_L) x = (x << 8) | next();
+              return (int)v;
+            };
+            int val = bits2(), nb = val;
+            while (val == 3 && !err) {
+              val = bits2();
+              nb += val;
+            }
+            int raw = 0;
+            for (int j = 0; j < nb && j < 16; ++j) raw |= bits2() << (2 * j);
+            value = raw >> 1;
+            value = (raw & 1) ? -value - 1 : value + max_value;
+          }
+          value += s_offs[ci];
+        }
       }
-      int raw = 0;
-      for (int j = 0; j < nb && j < 16; ++j) raw |= bits2() << (2 * j);
-      value = raw >> 1;
-      value = (raw & 1) ? -value - 1 : value + max_value;
+      if (lane == k) my_val = value;
     }
-    out[i] = (int16_t)(value + offsets[ci]);
+    if (lane < cnt) out[base + lane] = (int16_t)my_val;
   }
-  state[b * 4 + 0] = x;
-  state[b * 4 + 1] = (uint32_t)c.pos;
-  state[b * 4 + 2] = (uint32_t)c.err;
+  if (lane == 0) {
+    state[b * 4 + 0] = x;
+    state[b * 4 + 1] = (uint32_t)pos;
+    state[b * 4 + 2] = (uint32_t)err;
+  }
 }
 
 extern "C" int sgic_rans_decode_init_batch(const uint8_t *d_streams, int cap, const int32_t *d_off,
@@ -361,10 +393,19 @@ extern "C" int sgic_rans_decode_batch(const sgic_cdf_table *t, const uint8_t *d_
                                       int out_stride, sgic_stream_t stream) {
   SGIC_REQUIRE(t && d_streams && d_len && d_state && d_idx && d_sym_out && B > 0 && n >= 0, "args");
   SGIC_REQUIRE(idx_stride >= n && out_stride >= n, "strides");
-  // one lane per image; spread images over CUs (1 lane per workgroup keeps each stream on its own CU)
-  rans_decode_kernel<<<B, 1, 0, to_stream(stream)>>>(t->d_cdf, t->d_sizes, t->d_offsets, t->rows, t->cols, d_streams,
-                                                      cap, d_off, d_len, B, d_state, d_idx, n, idx_stride, d_sym_out,
-                                                      out_stride);
+  SGIC_REQUIRE(t->cols <= 128, "the lane-parallel cdf probe covers rows of at most 128 entries");
+  // one workgroup per image: table + stream window in LDS (dynamic: 105 KB for the 256 x 103 table)
+  const size_t lds = ((size_t)t->rows * t->cols + 2 * (size_t)t->rows) * sizeof(int32_t) + DEC_WIN;
+  SGIC_REQUIRE(lds <= 160 * 1024, "cdf table does not fit the 160 KB LDS");
+  static size_t lds_set = 0;
+  if (lds > lds_set) {
+    SGIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rans_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds));
+    lds_set = lds;
+  }
+  rans_decode_kernel<<<B, 256, lds, to_stream(stream)>>>(t->d_cdf, t->d_sizes, t->d_offsets, t->rows, t->cols, d_streams,
+                                                          cap, d_off, d_len, B, d_state, d_idx, n, idx_stride, d_sym_out,
+                                                          out_stride);
   return sgic::check_launch("rans_decode_kernel");
 }
 
