@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "common.h"
+#include <limits.h>
 
 namespace sgic {
 static thread_local char g_err[512] = "";
@@ -66,7 +67,7 @@ extern "C" int sgic_pmf_to_quantized_cdf(const float *pmf, int n, int precision,
 struct sgic_cdf_table {
   int rows, cols;
   uint32_t *d_enc;    // rows*cols  start | freq << 16
-  int32_t *d_cdf;     // rows*cols  raw cdf (decoder search)
+  int32_t *d_cdf;     // rows*cols  cdf, INT_MAX past each row's length (decoder probe)
   int32_t *d_sizes;   // rows
   int32_t *d_offsets; // rows
 };
@@ -92,7 +93,12 @@ extern "C" int sgic_cdf_table_create(const int32_t *cdf, int rows, int cols, con
   SGIC_HIP(hipMalloc(&t->d_sizes, rows * 4));
   SGIC_HIP(hipMalloc(&t->d_offsets, rows * 4));
   SGIC_HIP(hipMemcpy(t->d_enc, enc.data(), nb, hipMemcpyHostToDevice));
-  SGIC_HIP(hipMemcpy(t->d_cdf, cdf, nb, hipMemcpyHostToDevice));
+  // decoder image of the table: entries past a row's length are INT_MAX, so the lane-parallel probe "row[j] <= cum"
+  // needs no row length (it is also false for the final entry 65536, cum being 16 bits)
+  std::vector<int32_t> padded(cdf, cdf + (size_t)rows * cols);
+  for (int r = 0; r < rows; r++)
+    for (int v = sizes[r]; v < cols; v++) padded[(size_t)r * cols + v] = INT_MAX;
+  SGIC_HIP(hipMemcpy(t->d_cdf, padded.data(), nb, hipMemcpyHostToDevice));
   SGIC_HIP(hipMemcpy(t->d_sizes, sizes, rows * 4, hipMemcpyHostToDevice));
   SGIC_HIP(hipMemcpy(t->d_offsets, offsets, rows * 4, hipMemcpyHostToDevice));
   *out = t;
@@ -306,24 +312,46 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const int32_t *__restr
   const int off = d_off ? d_off[b] : 0;
   const uint8_t *sp = streams + (size_t)b * cap + off;
   const int len = d_len[b], pos0 = (int)state[b * 4 + 1];
-  for (int i = tid; i < rows * cols; i += 256) s_cdf[i] = cdf[i];
+  {  // the table image is already padded with INT_MAX past each row's length (sgic_cdf_table_create)
+    const int total = rows * cols, n4 = ((reinterpret_cast<uintptr_t>(cdf) & 15) == 0) ? total >> 2 : 0;
+    for (int i = tid; i < n4; i += 256) reinterpret_cast<int4 *>(s_cdf)[i] = reinterpret_cast<const int4 *>(cdf)[i];
+    for (int i = n4 * 4 + tid; i < total; i += 256) s_cdf[i] = cdf[i];
+  }
   for (int i = tid; i < rows; i += 256) s_size[i] = sizes[i], s_offs[i] = offsets[i];
   for (int i = tid; i < DEC_WIN; i += 256) s_win[i] = (pos0 + i < len) ? sp[pos0 + i] : (uint8_t)0;
   __syncthreads();
   if (tid >= 64) return;
 
-  // every lane of wave 0 carries the same cursor (uniform control flow); only the cdf probe is lane-parallel
+  // every lane of wave 0 carries the same cursor (uniform control flow); the cdf row and the next 64 stream bytes
+  // live one element per lane and are picked with v_readlane, so the serial chain per symbol is
+  // probe (prefetched) -> ballot -> readlane x2 -> multiply-add -> renormalise.
   uint32_t x = state[b * 4 + 0];
   int pos = pos0, err = (int)state[b * 4 + 2];
+  int wb = 0;  // base of the 64-byte block held in my_byte, relative to pos0
+  auto load_block = [&]() -> uint32_t {
+    const int w = wb + lane;
+    return (w < DEC_WIN) ? (uint32_t)s_win[w] : ((pos0 + w < len) ? (uint32_t)sp[pos0 + w] : 0u);
+  };
+  uint32_t my_byte = load_block();
   auto next = [&]() -> uint32_t {
-    if (pos < len) {
-      const int w = pos - pos0;
-      const uint32_t v = (w < DEC_WIN) ? s_win[w] : sp[pos];
-      ++pos;
-      return v;
+    if (pos >= len) {
+      err = 1;  // the reference over-reads silently (rans.cpp:53-68); we flag it
+      return 0;
     }
-    err = 1;  // the reference over-reads silently (rans.cpp:53-68); we flag it
-    return 0;
+    const int w = pos - pos0;
+    if (w - wb >= 64) {
+      wb += 64;
+      my_byte = load_block();
+    }
+    ++pos;
+    return (uint32_t)__builtin_amdgcn_readlane((int)my_byte, __builtin_amdgcn_readfirstlane(w - wb));
+  };
+  auto probe = [&](int ci, int32_t &v0, int32_t &v1, int &sz) {
+    const int cc = (ci >= 0 && ci < rows) ? ci : 0;
+    const int32_t *row = s_cdf + cc * cols;
+    v0 = lane < cols ? row[lane] : INT_MAX;
+    v1 = lane + 64 < cols ? row[lane + 64] : INT_MAX;
+    sz = s_size[cc];
   };
   idx += (size_t)b * idx_stride;
   out += (size_t)b * out_stride;
@@ -331,25 +359,33 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const int32_t *__restr
     const int cnt = min(64, n - base);
     const int my_ci = (lane < cnt) ? (int)idx[base + lane] : -1;
     int my_val = 0;
+    int ci_n = __builtin_amdgcn_readlane(my_ci, 0);
+    int32_t v0n, v1n;
+    int szn;
+    probe(ci_n, v0n, v1n, szn);
     for (int k = 0; k < cnt; ++k) {
-      const int ci = __shfl(my_ci, k);
+      const int ci = ci_n;
+      const int32_t v0 = v0n, v1 = v1n;
+      const int max_value = szn - 2;
+      if (k + 1 < cnt) {  // next symbol's row is fetched while this one is decoded
+        ci_n = __builtin_amdgcn_readlane(my_ci, __builtin_amdgcn_readfirstlane(k + 1));
+        probe(ci_n, v0n, v1n, szn);
+      }
       int value = 0;
       if (ci >= 0) {
         if (ci >= rows || err) {
           err = err ? err : 3;
         } else {
-          const int32_t *row = s_cdf + ci * cols;
-          const int size = s_size[ci], max_value = size - 2;
           const uint32_t cum = x & 0xffffu;
           // number of j with row[j] <= cum  ==  (largest such j) + 1 ; row[0] = 0 so it is >= 1
-          const bool p0 = lane < size && (uint32_t)row[lane] <= cum;
-          const bool p1 = lane + 64 < size && (uint32_t)row[lane + 64] <= cum;
-          const int lo = __popcll(__ballot(p0)) + __popcll(__ballot(p1)) - 1;
-          const uint32_t start = (uint32_t)row[lo], freq = (uint32_t)row[lo + 1] - start;
-          x = freq * (x >> 16) + cum - start;
+          const int lo = __builtin_amdgcn_readfirstlane(__popcll(__ballot(v0 <= (int32_t)cum)) + __popcll(__ballot(v1 <= (int32_t)cum)) - 1);
+          const int hi = lo + 1;
+          const uint32_t start = (uint32_t)(lo < 64 ? __builtin_amdgcn_readlane(v0, lo & 63) : __builtin_amdgcn_readlane(v1, lo & 63));
+          const uint32_t end = (uint32_t)(hi < 64 ? __builtin_amdgcn_readlane(v0, hi & 63) : __builtin_amdgcn_readlane(v1, hi & 63));
+          x = (end - start) * (x >> 16) + cum - start;
           while (x < RANS_L) x = (x << 8) | next();
           value = lo;
-          if (value == max_value) {
+          if (value == max_value) {  // the last bin of a row is the bypass sentinel
             auto bits2 = [&]() {
               uint32_t v = x & 3u;
               x >>= 2;
