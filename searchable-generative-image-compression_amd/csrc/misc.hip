@@ -164,11 +164,69 @@ __global__ void dwconv_kernel(const float *__restrict__ x, const float *__restri
   }
 }
 
+// Same convolution, four output pixels of one row per thread: the KS + 3 input float4s of a kernel row are loaded
+// once and shared by the four outputs (65 loads per 4 outputs at 5x5 instead of 200).  Per output the taps are still
+// accumulated in (ky, kx) order with separate multiply and add, so the result is bit-identical to dwconv_kernel
+// (out-of-range taps contribute an exact zero).
+template <int KS>
+__global__ __launch_bounds__(256) void dwconv_x4_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                        const float *__restrict__ bias, const float *__restrict__ prescale,
+                                                        float *__restrict__ y, int B, int H, int W, int C, int tile16) {
+  constexpr int pad = KS >> 1;
+  const int C4 = C >> 2, XG = W >> 2;
+  const long total = (long)B * H * XG * C4;
+  // XCD-aware order: workgroup ids are dealt round-robin over the 8 XCDs (each with its own L2); give every XCD a
+  // contiguous eighth of the work so the KS rows a pixel needs are fetched into ONE L2 instead of up to KS of them
+  long blk = blockIdx.x;
+  if ((gridDim.x & 7) == 0) blk = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  for (long i = blk * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    long t = i / C4;
+    const int x0 = (int)(t % XG) * 4;
+    t /= XG;
+    const int yy = (int)(t % H);
+    const int b = (int)(t / H);
+    const f32x4 bz = bias ? reinterpret_cast<const f32x4 *>(bias)[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 ps = prescale ? reinterpret_cast<const f32x4 *>(prescale)[c4] : f32x4{1.f, 1.f, 1.f, 1.f};
+    f32x4 acc[4] = {bz, bz, bz, bz};
+#pragma unroll
+    for (int ky = 0; ky < KS; ky++) {
+      const int sy = yy + ky - pad;
+      if (sy < 0 || sy >= H) continue;
+      f32x4 in[KS + 3];
+#pragma unroll
+      for (int j = 0; j < KS + 3; j++) {
+        const int sx = x0 + j - pad;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (sx >= 0 && sx < W) {
+          v = reinterpret_cast<const f32x4 *>(x + fmap_row(b, sy, sx, H, W, tile16) * C)[c4];
+          if (prescale) v *= ps;
+        }
+        in[j] = v;
+      }
+#pragma unroll
+      for (int kx = 0; kx < KS; kx++) {
+        const f32x4 wv = reinterpret_cast<const f32x4 *>(w + (long)(ky * KS + kx) * C)[c4];
+#pragma unroll
+        for (int o = 0; o < 4; o++) acc[o] += in[o + kx] * wv;
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; o++) reinterpret_cast<f32x4 *>(y + fmap_row(b, yy, x0 + o, H, W, tile16) * C)[c4] = acc[o];
+  }
+}
+
 extern "C" int sgic_dwconv_nhwc(const float *d_x, const float *d_w, const float *d_bias, const float *d_prescale,
                                 float *d_y, int B, int H, int W, int C, int k, int tile16, sgic_stream_t stream) {
   SGIC_REQUIRE(d_x && d_w && d_y && d_x != d_y && B > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && (k & 1) == 1, "args");
   SGIC_REQUIRE(!tile16 || (H % 16 == 0 && W % 16 == 0), "tile-major layout needs H,W multiples of 16");
   const long total = (long)B * H * W * (C / 4);
+  if ((W & 3) == 0 && (k == 3 || k == 5)) {
+    const unsigned grid = (unsigned)((total / 4 + 255) / 256);   // one pass, no grid stride: the XCD remap needs the exact grid
+    if (k == 5) dwconv_x4_kernel<5><<<grid, 256, 0, to_stream(stream)>>>(d_x, d_w, d_bias, d_prescale, d_y, B, H, W, C, tile16);
+    else dwconv_x4_kernel<3><<<grid, 256, 0, to_stream(stream)>>>(d_x, d_w, d_bias, d_prescale, d_y, B, H, W, C, tile16);
+    return sgic::check_launch("dwconv_x4_kernel");
+  }
   dwconv_kernel<<<ew_grid(total), 256, 0, to_stream(stream)>>>(d_x, d_w, d_bias, d_prescale, d_y, B, H, W, C, k, tile16);
   return sgic::check_launch("dwconv_kernel");
 }
