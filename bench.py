@@ -179,6 +179,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    ops.finalize_autotune()   # close pending in-context tile races: no tuning work inside the timed region
     ops.PROFILE = []
     sync()
     t0 = time.perf_counter()

@@ -57,9 +57,53 @@ def _tune(key, launch):
             t = e0.elapsed_time(e1)
             times[mode] = min(t, times.get(mode, t))
     lib.sgic_gemm_set_tile(0)
-    best = min(times, key=times.get)
+    order = sorted(times, key=times.get)
+    best = order[0]
     _TILE[key] = best
+    # second stage, in context: the leaders of the isolated race (within 6 % of the best) are re-timed on the next real
+    # occurrences of this shape, i.e. with the caches in the state the surrounding kernels leave them in
+    cands = [m for m in order[:CTX_CANDS] if times[m] <= 1.06 * times[best]]
+    if CTX_REPS > 0 and len(cands) > 1 and M_big(key):
+        _CTX[key] = {"cands": cands, "t": {m: [] for m in cands}, "i": 0}
     return best
+
+
+CTX_CANDS, CTX_REPS = 3, 2
+_CTX = {}
+
+
+def M_big(key):
+    """in-context re-timing synchronises the stream once per sample: only worth it for launches of >= ~50 us"""
+    if key and key[0] == "conv3x3":
+        return True
+    return 2.0 * key[0] * key[1] * key[2] >= 5e9
+
+
+def _ctx_launch(key, launch):
+    """one in-context sample of the next candidate mode; picks the winner when every candidate has CTX_REPS samples"""
+    c = _CTX[key]
+    mode = c["cands"][c["i"] % len(c["cands"])]
+    c["i"] += 1
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    lib.sgic_gemm_set_tile(mode)
+    e0.record()
+    launch()
+    e1.record()
+    lib.sgic_gemm_set_tile(0)
+    e1.synchronize()
+    c["t"][mode].append(e0.elapsed_time(e1))
+    if c["i"] >= len(c["cands"]) * CTX_REPS:
+        _TILE[key] = min(c["cands"], key=lambda m: min(c["t"][m]))
+        del _CTX[key]
+
+
+def finalize_autotune():
+    """close every pending in-context race with the samples it has (call before a timed region)"""
+    for key in list(_CTX):
+        c = _CTX.pop(key)
+        done = [m for m in c["cands"] if c["t"][m]]
+        if done:
+            _TILE[key] = min(done, key=lambda m: min(c["t"][m]))
 
 
 def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(0, 0), c_seg=(0, 0)):
@@ -100,6 +144,9 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(
                 out.copy_(saved)
             else:
                 tile = _tune(key, launch)
+        elif key in _CTX and PROFILE is None:
+            _ctx_launch(key, launch)
+            return out
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -329,6 +376,9 @@ def conv3x3(x_halo, w, bias, B, H, W, Cin, Cout, residual=None, act=ACT_NONE, ou
         tile = _TILE.get(key)
         if tile is None:
             tile = _tune(key, launch)     # conv outputs never alias their residual: re-running is idempotent
+        elif key in _CTX and PROFILE is None:
+            _ctx_launch(key, launch)
+            return out
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
