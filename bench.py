@@ -179,8 +179,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ops.finalize_autotune()   # close pending in-context tile races: no tuning work inside the timed region
-    ops.PROFILE = []
+    # profile window: closes pending in-context tile races (no tuning inside the timed region) and times every GEMM /
+    # conv launch with its own dispatch-level event pair (hipExtLaunchKernel, no extra packets on the stream)
+    ops.profile_begin()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -188,7 +189,7 @@ def main():
     out = drain() or out      # the last step's host work is inside the timed region too
     sync()
     dt = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
+    prof = ops.profile_end()      # [(flops, ms, shape key)] per launch of the timed region
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -196,12 +197,11 @@ def main():
 
     if rank == 0:
         gemm_flops = sum(p[0] for p in prof)
-        gemm_ms = sum(p[1].elapsed_time(p[2]) for p in prof)
+        gemm_ms = sum(p[1] for p in prof)
         n_launch = len(prof)
         if os.environ.get("SGIC_BENCH_SHAPES"):   # per-shape breakdown of the dominant kernel (stderr)
             agg = {}
-            for fl, a_, b_, key in prof:
-                t_ = a_.elapsed_time(b_)
+            for fl, t_, key in prof:
                 v = agg.setdefault(key, [0.0, 0.0, 0])
                 v[0] += fl; v[1] += t_; v[2] += 1
             for key, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):

@@ -122,6 +122,13 @@ int sgic_gemm_f32(const float *d_A, int lda, const float *d_W, int ldw, const fl
  * autotuner (sgic_amd.ops) uses it to pick the faster tile per GEMM shape. */
 int sgic_gemm_set_tile(int mode);
 
+/* Profile window for the roofline figure of bench.py: between begin and end every sgic_gemm_f32 / sgic_gemm_batched_f32 /
+ * sgic_conv3x3_f32 launch is dispatched with its own (start, stop) event pair (hipExtLaunchKernel: the timestamps are
+ * taken by the dispatch itself, no extra packets on the stream).  end() closes the window and returns the duration in
+ * milliseconds of each launch in launch order (at most max_launches of them). */
+int sgic_gemm_profile_begin(int max_launches);
+int sgic_gemm_profile_end(float *ms_out, int cap, int *n_out);
+
 /* Row LayerNorm, biased variance, eps inside sqrt, optional fused SiLU (act = SGIC_ACT_SILU); rows of x
  * and y addressed through the same kind of segment map (titok/blocks.py:36,42,
  * blocks/swin_transformer.py:135,142, blocks/conv_blocks.py:62, models/cross_blocks.py:62,67). */

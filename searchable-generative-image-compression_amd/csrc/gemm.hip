@@ -27,6 +27,10 @@
 //    (M = 9248 = 72.25 tiles is never a multiple of the machine).
 #include <math.h>
 
+#include <vector>
+
+#include <hip/hip_ext.h>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -451,6 +455,49 @@ extern "C" int sgic_gemm_set_tile(int mode) {
   return SGIC_OK;
 }
 
+// Per-launch timing without extra packets on the stream: while a profile window is open every GEMM / conv launch goes
+// through hipExtLaunchKernel with its own (start, stop) event pair, i.e. the timestamps are taken by the dispatch itself
+// (bench.py's live roofline figure).  Bracketing each launch with hipEventRecord instead costs ~2 us of stream time
+// per event -- 1.5 % of a compress step at 360 launches.
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
+static int g_prof_n = -1;  // -1: closed
+
+extern "C" int sgic_gemm_profile_begin(int max_launches) {
+  SGIC_REQUIRE(max_launches > 0, "max_launches");
+  while ((int)g_prof_pool.size() < max_launches) {
+    hipEvent_t a, b;
+    SGIC_HIP(hipEventCreate(&a));
+    SGIC_HIP(hipEventCreate(&b));
+    g_prof_pool.emplace_back(a, b);
+  }
+  g_prof_n = 0;
+  return SGIC_OK;
+}
+
+// closes the window; ms_out[i] = duration of the i-th launch since sgic_gemm_profile_begin (device must be idle or the
+// events complete: the call synchronises on the last stop event)
+extern "C" int sgic_gemm_profile_end(float *ms_out, int cap, int *n_out) {
+  SGIC_REQUIRE(g_prof_n >= 0 && n_out, "no open profile window");
+  const int total = g_prof_n, n = total < cap ? total : cap;
+  g_prof_n = -1;
+  for (int i = 0; i < n; i++) {
+    SGIC_HIP(hipEventSynchronize(g_prof_pool[i].second));
+    SGIC_HIP(hipEventElapsedTime(&ms_out[i], g_prof_pool[i].first, g_prof_pool[i].second));
+  }
+  *n_out = total;  // launches seen in the window (the caller compares it with its own count)
+  return SGIC_OK;
+}
+
+template <typename K>
+static inline void launch_gemm(K kernel, dim3 grid, hipStream_t st, const GemmArgs &g) {
+  if (g_prof_n >= 0 && g_prof_n < (int)g_prof_pool.size()) {
+    const auto &ev = g_prof_pool[g_prof_n++];
+    hipExtLaunchKernelGGL(kernel, grid, dim3(256), 0, st, ev.first, ev.second, 0, g);
+  } else {
+    kernel<<<grid, 256, 0, st>>>(g);
+  }
+}
+
 static int gemm_launch(GemmArgs g, int batch, hipStream_t st) {
   const int M = g.M, N = g.N, K = g.K;
   // Tile choice: 128x128 unless the 128x64 grid fills the last round of workgroups on the 256 CUs clearly
@@ -505,22 +552,22 @@ static int gemm_launch(GemmArgs g, int batch, hipStream_t st) {
     grid.x = ((M + 63) / 64) * ((N + 63) / 64);
     g.big_blocks = (int)grid.x;
     g.stagger_cycles = 0;
-    if (single) gemm_f32_kernel<1, 1, false, 1, false, false><<<grid, 256, 0, st>>>(g);
-    else gemm_f32_kernel<1, 1, false, 2, false, false><<<grid, 256, 0, st>>>(g);
+    if (single) launch_gemm(gemm_f32_kernel<1, 1, false, 1, false, false>, grid, st, g);
+    else launch_gemm(gemm_f32_kernel<1, 1, false, 2, false, false>, grid, st, g);
   } else if (persist) {
-    if (mixed) gemm_f32_kernel<2, 2, false, 2, true, true><<<grid, 256, 0, st>>>(g);
-    else gemm_f32_kernel<2, 2, false, 2, false, true><<<grid, 256, 0, st>>>(g);
+    if (mixed) launch_gemm(gemm_f32_kernel<2, 2, false, 2, true, true>, grid, st, g);
+    else launch_gemm(gemm_f32_kernel<2, 2, false, 2, false, true>, grid, st, g);
   } else if (mixed) {
-    if (single) gemm_f32_kernel<2, 2, false, 1, true, false><<<grid, 256, 0, st>>>(g);
-    else gemm_f32_kernel<2, 2, false, 2, true, false><<<grid, 256, 0, st>>>(g);
+    if (single) launch_gemm(gemm_f32_kernel<2, 2, false, 1, true, false>, grid, st, g);
+    else launch_gemm(gemm_f32_kernel<2, 2, false, 2, true, false>, grid, st, g);
   } else if (narrow) {
-    if (ktail) gemm_f32_kernel<2, 1, true, 2, false, false><<<grid, 256, 0, st>>>(g);
-    else if (single) gemm_f32_kernel<2, 1, false, 1, false, false><<<grid, 256, 0, st>>>(g);
-    else gemm_f32_kernel<2, 1, false, 2, false, false><<<grid, 256, 0, st>>>(g);
+    if (ktail) launch_gemm(gemm_f32_kernel<2, 1, true, 2, false, false>, grid, st, g);
+    else if (single) launch_gemm(gemm_f32_kernel<2, 1, false, 1, false, false>, grid, st, g);
+    else launch_gemm(gemm_f32_kernel<2, 1, false, 2, false, false>, grid, st, g);
   } else {
-    if (ktail) gemm_f32_kernel<2, 2, true, 2, false, false><<<grid, 256, 0, st>>>(g);
-    else if (single) gemm_f32_kernel<2, 2, false, 1, false, false><<<grid, 256, 0, st>>>(g);
-    else gemm_f32_kernel<2, 2, false, 2, false, false><<<grid, 256, 0, st>>>(g);
+    if (ktail) launch_gemm(gemm_f32_kernel<2, 2, true, 2, false, false>, grid, st, g);
+    else if (single) launch_gemm(gemm_f32_kernel<2, 2, false, 1, false, false>, grid, st, g);
+    else launch_gemm(gemm_f32_kernel<2, 2, false, 2, false, false>, grid, st, g);
   }
   return sgic::check_launch("gemm_f32_kernel");
 }
@@ -627,7 +674,13 @@ extern "C" int sgic_conv3x3_f32(const float *d_in_halo, const float *d_W, const 
   SGIC_REQUIRE(Cin % BK == 0, "implicit-GEMM conv needs Cin % 32 == 0");
   if (Cout == 3 && Cin == 128 && !d_R) {
     const unsigned grid = (unsigned)min((Ml + 7) / 8, 256L * 32);
-    conv3x3_thin_kernel<3><<<grid, 256, 0, to_stream(stream)>>>(d_in_halo, d_W, d_bias, d_out, ldc, Ml, H, W, act);
+    if (g_prof_n >= 0 && g_prof_n < (int)g_prof_pool.size()) {
+      const auto &ev = g_prof_pool[g_prof_n++];
+      hipExtLaunchKernelGGL(conv3x3_thin_kernel<3>, dim3(grid), dim3(256), 0, to_stream(stream), ev.first, ev.second, 0,
+                            d_in_halo, d_W, d_bias, d_out, ldc, Ml, H, W, act);
+    } else {
+      conv3x3_thin_kernel<3><<<grid, 256, 0, to_stream(stream)>>>(d_in_halo, d_W, d_bias, d_out, ldc, Ml, H, W, act);
+    }
     return sgic::check_launch("conv3x3_thin_kernel");
   }
   GemmArgs g{d_in_halo, d_W, d_bias, d_R, d_out, M, Cout, K, Cin, K, ldr, ldc, act, 0, 0, 0, 0,

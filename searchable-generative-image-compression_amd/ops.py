@@ -4,13 +4,33 @@ import ctypes
 
 import torch
 
-from ._lib import call, lib, require_gpu
+from ._lib import call, check, lib, require_gpu
 
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_TANH, ACT_LRELU = 0, 1, 2, 3, 4
 
 # Optional live profiling of the dominant kernel (bench.py): when PROFILE is a list, every gemm() launch is
 # bracketed by HIP events on the launch stream and (flops, start, end) is appended.
 PROFILE = None
+
+
+def profile_begin(max_launches=8192):
+    """open a profile window: every GEMM / conv launch from now on is timed by its own dispatch (sgic_gemm_profile_begin)"""
+    global PROFILE
+    finalize_autotune()
+    check(lib.sgic_gemm_profile_begin(int(max_launches)), "sgic_gemm_profile_begin")
+    PROFILE = []
+
+
+def profile_end():
+    """close the window -> list of (flops, milliseconds, shape key) per launch, in launch order"""
+    global PROFILE
+    recs, PROFILE = PROFILE, None
+    buf = (ctypes.c_float * max(1, len(recs)))()
+    n = ctypes.c_int(0)
+    check(lib.sgic_gemm_profile_end(buf, len(recs), ctypes.byref(n)), "sgic_gemm_profile_end")
+    if n.value != len(recs):
+        raise RuntimeError(f"profile window: {len(recs)} launches recorded on the host, {n.value} timed on the device")
+    return [(fl, float(buf[i]), key) for i, (fl, key) in enumerate(recs)]
 
 
 def _rows(t):
@@ -136,7 +156,9 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(
     if AUTOTUNE and M * N >= (1 << 16):
         key = (M, N, K, residual is not None, act, str(a.device))
         tile = _TILE.get(key)
-        if tile is None:
+        if tile is None and PROFILE is not None:
+            tile = 0      # never tune inside a profile window (its probes would take event slots): built-in heuristic
+        elif tile is None:
             # in-place residual GEMMs (out is residual) are not idempotent: save / restore the buffer around tuning
             if residual is not None and out.data_ptr() == residual.data_ptr():
                 saved = out.clone()
@@ -147,17 +169,13 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(
         elif key in _CTX and PROFILE is None:
             _ctx_launch(key, launch)
             return out
-    if PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
     if tile:
         lib.sgic_gemm_set_tile(tile)
     launch()
     if tile:
         lib.sgic_gemm_set_tile(0)
-    if PROFILE is not None:
-        e1.record()
-        PROFILE.append((2.0 * M * N * K, e0, e1, (M, N, K, residual is not None, act)))
+    if PROFILE is not None:   # the launch took the next event pair of the open profile window (profile_begin)
+        PROFILE.append((2.0 * M * N * K, (M, N, K, residual is not None, act)))
     return out
 
 
@@ -374,22 +392,20 @@ def conv3x3(x_halo, w, bias, B, H, W, Cin, Cout, residual=None, act=ACT_NONE, ou
     if AUTOTUNE and B * H * W * Cout >= (1 << 20):
         key = ("conv3x3", B, H, W, Cin, Cout, residual is not None, act, str(x_halo.device))
         tile = _TILE.get(key)
-        if tile is None:
+        if tile is None and PROFILE is not None:
+            tile = 0
+        elif tile is None:
             tile = _tune(key, launch)     # conv outputs never alias their residual: re-running is idempotent
         elif key in _CTX and PROFILE is None:
             _ctx_launch(key, launch)
             return out
-    if PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
     if tile:
         lib.sgic_gemm_set_tile(tile)
     launch()
     if tile:
         lib.sgic_gemm_set_tile(0)
     if PROFILE is not None:   # the implicit-GEMM convolution is the same kernel: M = B*H*W, N = Cout, K = 9*Cin
-        e1.record()
-        PROFILE.append((2.0 * B * H * W * Cout * 9 * Cin, e0, e1, (B * H * W, Cout, 9 * Cin, residual is not None, act)))
+        PROFILE.append((2.0 * B * H * W * Cout * 9 * Cin, (B * H * W, Cout, 9 * Cin, residual is not None, act)))
     return out
 
 

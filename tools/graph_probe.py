@@ -34,9 +34,9 @@ def timeit(fn, n=5):
 
 
 print("eager   ms/forward", timeit(lambda: enc.forward(x)), flush=True)
-ops.PROFILE = []
+ops.profile_begin()
 print("eager+events ms/forward", timeit(lambda: enc.forward(x)), flush=True)
-ops.PROFILE = None
+ops.profile_end()
 g = torch.cuda.CUDAGraph()
 s = torch.cuda.Stream()
 s.wait_stream(torch.cuda.current_stream())
