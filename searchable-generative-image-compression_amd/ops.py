@@ -372,6 +372,8 @@ def gemm_batched(a, lda, sa, w, ldw, sw, out, ldc, sc, M, N, K, batch, bias=None
     """batch of GEMMs on raw pointers/strides (elements); a, w, out, residual are tensors used as base pointers"""
     call("sgic_gemm_batched_f32", _p(a), lda, _cl(sa), _p(w), ldw, _cl(sw), _p(bias), _p(residual), ldr, _cl(sr), _p(out), ldc,
          _cl(sc), M, N, K, act, batch)
+    if PROFILE is not None:
+        PROFILE.append((2.0 * M * N * K * batch, ("batched", batch, M, N, K, residual is not None, act)))
     return out
 
 
