@@ -225,3 +225,22 @@ def test_clip_text_tower_vs_torch_ref(name):
     assert torch.equal(model.encode_text(t2).cpu()[1], unit[1])
     with pytest.raises(ValueError):
         model.encode_text(toks[:, :-1])
+
+
+def test_profile_window_times_every_gemm_launch():
+    """sgic_gemm_profile_begin/end (bench.py's roofline figure): one duration per GEMM / conv launch, in launch order"""
+    import sgic_amd  # noqa
+    from sgic_amd import ops
+    a = torch.randn(2048, 512, device="cuda:0")
+    w = torch.randn(1024, 512, device="cuda:0")
+    ref = ops.gemm(a, w)
+    ops.profile_begin(16)
+    outs = [ops.gemm(a, w) for _ in range(3)]
+    small = ops.gemm(a[:64], w[:64])
+    recs = ops.profile_end()
+    assert ops.PROFILE is None and len(recs) == 4
+    assert all(ms > 0.0 for _, ms, _ in recs) and recs[0][0] == 2.0 * 2048 * 1024 * 512 and recs[3][2][:3] == (64, 64, 512)
+    assert recs[3][1] < recs[0][1]                       # the 64x64 GEMM is the short one
+    assert all(torch.equal(o, ref) for o in outs) and torch.equal(small, ref[:64, :64])
+    with pytest.raises(Exception):
+        ops.profile_end()                                 # no open window
