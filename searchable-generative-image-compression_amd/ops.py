@@ -24,6 +24,8 @@ def profile_begin(max_launches=8192):
 def profile_end():
     """close the window -> list of (flops, milliseconds, shape key) per launch, in launch order"""
     global PROFILE
+    if PROFILE is None:
+        raise RuntimeError("profile_end() without an open profile window")
     recs, PROFILE = PROFILE, None
     buf = (ctypes.c_float * max(1, len(recs)))()
     n = ctypes.c_int(0)
