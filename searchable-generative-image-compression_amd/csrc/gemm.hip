@@ -478,7 +478,7 @@ extern "C" int sgic_gemm_profile_begin(int max_launches) {
 // events complete: the call synchronises on the last stop event)
 extern "C" int sgic_gemm_profile_end(float *ms_out, int cap, int *n_out) {
   SGIC_REQUIRE(g_prof_n >= 0 && n_out, "no open profile window");
-  const int total = g_prof_n, n = total < cap ? total : cap;
+  const int total = g_prof_n, n = total < cap ? total : cap;   // total <= pool size: prof_next grows the pool first
   g_prof_n = -1;
   for (int i = 0; i < n; i++) {
     SGIC_HIP(hipEventSynchronize(g_prof_pool[i].second));
@@ -488,10 +488,22 @@ extern "C" int sgic_gemm_profile_end(float *ms_out, int cap, int *n_out) {
   return SGIC_OK;
 }
 
+// next event pair of the open window (the pool grows on demand), or null when no window is open
+static const std::pair<hipEvent_t, hipEvent_t> *prof_next() {
+  if (g_prof_n < 0) return nullptr;
+  while (g_prof_n >= (int)g_prof_pool.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess) return nullptr;
+    if (hipEventCreate(&b) != hipSuccess) return nullptr;
+    g_prof_pool.emplace_back(a, b);
+  }
+  return &g_prof_pool[g_prof_n++];
+}
+
 template <typename K>
 static inline void launch_gemm(K kernel, dim3 grid, hipStream_t st, const GemmArgs &g) {
-  if (g_prof_n >= 0 && g_prof_n < (int)g_prof_pool.size()) {
-    const auto &ev = g_prof_pool[g_prof_n++];
+  if (const auto *evp = prof_next()) {
+    const auto &ev = *evp;
     hipExtLaunchKernelGGL(kernel, grid, dim3(256), 0, st, ev.first, ev.second, 0, g);
   } else {
     kernel<<<grid, 256, 0, st>>>(g);
@@ -674,8 +686,8 @@ extern "C" int sgic_conv3x3_f32(const float *d_in_halo, const float *d_W, const 
   SGIC_REQUIRE(Cin % BK == 0, "implicit-GEMM conv needs Cin % 32 == 0");
   if (Cout == 3 && Cin == 128 && !d_R) {
     const unsigned grid = (unsigned)min((Ml + 7) / 8, 256L * 32);
-    if (g_prof_n >= 0 && g_prof_n < (int)g_prof_pool.size()) {
-      const auto &ev = g_prof_pool[g_prof_n++];
+    if (const auto *evp = prof_next()) {
+      const auto &ev = *evp;
       hipExtLaunchKernelGGL(conv3x3_thin_kernel<3>, dim3(grid), dim3(256), 0, to_stream(stream), ev.first, ev.second, 0,
                             d_in_halo, d_W, d_bias, d_out, ldc, Ml, H, W, act);
     } else {
