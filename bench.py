@@ -213,8 +213,9 @@ def main():
         # HBM-side bytes per GEMM launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2-corrected + WRITE_SIZE,
         # MI355X_MICROARCH.md) committed under profiles/; PMC counters cannot be read live from inside this process.
         traffic = None
+        pmc_file = "round1_pmc_gemm_summary.json" if args.mode == "compress" else "round1_pmc_decompress_gemm_summary.json"
         try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_gemm_summary.json")))
+            pj = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             traffic = int((pj["hbm_fetch_MB_per_launch_x2_corrected"] + pj["hbm_write_MB_per_launch"]) * 1e6)
         except Exception:
             pass
@@ -231,8 +232,8 @@ def main():
                         f"taming VQGAN decoder), {'SMALL debug model' if args.small else 'production architecture'}, synthetic weights"),
                        "global_batch": world * B, "bytes_per_image": round(total_bytes / B, 1)},
             "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic if args.mode == "compress" else None,
-                         "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/round1_pmc_gemm_summary.json)",
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": f"bytes per launch (rocprofv3 PMC, profiles/{pmc_file})",
                          "launches_per_step": n_launch // max(1, args.steps),
                          "avg_launch_us": round(gemm_ms * 1e3 / max(1, n_launch), 2),
                          "gflop_per_launch": round(gemm_flops / max(1, n_launch) / 1e9, 3),
