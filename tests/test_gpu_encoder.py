@@ -244,3 +244,54 @@ def test_profile_window_times_every_gemm_launch():
     assert all(torch.equal(o, ref) for o in outs) and torch.equal(small, ref[:64, :64])
     with pytest.raises(Exception):
         ops.profile_end()                                 # no open window
+
+
+def test_gemm_fuzz_all_tile_modes_identical_and_close_to_fp64():
+    """sgic_gemm_f32 over random shapes (ragged M/N, K with and without a 32-tail, bias / residual / activation /
+    row maps): all 14 launch modes give BITWISE the same result (fixed k order; persistent, mixed and 64x64 launches
+    included) and that result is within 3e-6 * sqrt(K) * max|ref| of an fp64 reference."""
+    import sgic_amd  # noqa
+    from sgic_amd import ops
+    from sgic_amd._lib import lib
+    rng = np.random.default_rng(11)
+    dev = torch.device("cuda:0")
+    old = ops.AUTOTUNE
+    ops.AUTOTUNE = False
+    try:
+        shapes = [(9248, 1024, 256), (289, 3072, 1024), (1600, 768, 96), (70000, 128, 128), (5000, 200, 64), (129, 132, 36)]
+        shapes += [(int(rng.integers(1, 3000)), int(rng.integers(1, 600)) * 4, int(rng.integers(1, 80)) * 4) for _ in range(10)]
+        for (M, N, K) in shapes:
+            a = torch.from_numpy(rng.standard_normal((M, K), dtype=np.float32)).to(dev)
+            w = torch.from_numpy(rng.standard_normal((N, K), dtype=np.float32)).to(dev)
+            b = torch.from_numpy(rng.standard_normal(N, dtype=np.float32)).to(dev)
+            res = torch.from_numpy(rng.standard_normal((M, N), dtype=np.float32)).to(dev) if rng.random() < 0.5 else None
+            act = int(rng.integers(0, 5))
+            outs = []
+            for mode in ops.TUNE_MODES:
+                lib.sgic_gemm_set_tile(mode)
+                outs.append(ops.gemm(a, w, b, residual=res, act=act))
+            lib.sgic_gemm_set_tile(0)
+            outs.append(ops.gemm(a, w, b, residual=res, act=act))             # built-in heuristic
+            assert all(torch.equal(o, outs[0]) for o in outs[1:]), (M, N, K, act)
+            pre = a.double() @ w.double().T + b.double()
+            f = {0: lambda v: v, 1: lambda v: torch.nn.functional.gelu(v), 2: lambda v: torch.nn.functional.silu(v), 3: torch.tanh,
+                 4: lambda v: torch.nn.functional.leaky_relu(v, 0.01)}[act]
+            ref = f(pre) + (res.double() if res is not None else 0.0)
+            err = float((outs[0].double() - ref).abs().max())
+            assert err < 3e-6 * (K ** 0.5) * max(1.0, float(pre.abs().max())), (M, N, K, act, err)
+        # row maps: write C into a token slice of a larger buffer, read A through a segment map (cross blocks)
+        n, L, Lr, D = 7, 40, 25, 64
+        buf = torch.zeros(n * L, D, device=dev)
+        a = torch.from_numpy(rng.standard_normal((n * L, 32), dtype=np.float32)).to(dev)
+        w = torch.from_numpy(rng.standard_normal((D, 32), dtype=np.float32)).to(dev)
+        for mode in (0, 1, 4, 11, 12, 13):
+            lib.sgic_gemm_set_tile(mode)
+            buf.zero_()
+            ops.gemm(a, w, out=buf, M=n * Lr, a_seg=(Lr, L), c_seg=(Lr, L))
+            lib.sgic_gemm_set_tile(0)
+            ref = (a.view(n, L, 32)[:, :Lr].double() @ w.double().T).float()
+            got = buf.view(n, L, D)
+            assert float((got[:, :Lr] - ref).abs().max()) < 1e-4 and float(got[:, Lr:].abs().max()) == 0.0, mode
+    finally:
+        lib.sgic_gemm_set_tile(0)
+        ops.AUTOTUNE = old
