@@ -295,3 +295,41 @@ def test_gemm_fuzz_all_tile_modes_identical_and_close_to_fp64():
     finally:
         lib.sgic_gemm_set_tile(0)
         ops.AUTOTUNE = old
+
+
+@pytest.mark.parametrize("L,nseq,heads,bias", [(289, 3, 4, False), (545, 2, 3, False), (256, 4, 2, True), (50, 5, 12, False),
+                                                 (33, 2, 1, False), (34, 2, 2, False), (2, 3, 1, False), (1, 2, 2, False), (100, 2, 2, True)])
+def test_attention_vs_torch(L, nseq, heads, bias):
+    """sgic_attention_f32 vs softmax(q k^T / 8 + bias) v in fp64 for every sequence-length class of the path: full
+    tiles, the 1-2 key ragged tail folded in on the VALU (L % 32 in {1, 2}), masked tails (other L), additive bias with
+    -inf entries, and every waves-per-workgroup setting.  Tolerance 2e-5 absolute on O(1) outputs."""
+    import sgic_amd  # noqa
+    from sgic_amd import ops
+    from sgic_amd._lib import lib
+    g = torch.Generator().manual_seed(L * 7 + heads)
+    D = heads * 64
+    qkv = torch.randn(nseq * L, 3 * D, generator=g)
+    b = None
+    if bias:
+        b = torch.randn(2, L, L, generator=g)
+        b[1, :, L // 3: L // 2] = float("-inf")            # a masked band (Swin shift masks contain -inf)
+    var = torch.arange(nseq, dtype=torch.int32) % 2
+    q, k, v = (qkv[:, i * D:(i + 1) * D].reshape(nseq, L, heads, 64).permute(0, 2, 1, 3).double() for i in range(3))
+    s = q @ k.transpose(-1, -2) * 0.125
+    if bias:
+        s = s + b[var.long()].double()[:, None]
+    ref = (torch.softmax(s, dim=-1) @ v).permute(0, 2, 1, 3).reshape(nseq * L, D)
+    d = qkv.cuda()
+    old = ops.AUTOTUNE
+    ops.AUTOTUNE = False
+    try:
+        for mw in (4, 8, 10):
+            lib.sgic_attention_set_max_waves(mw)
+            out = torch.empty(nseq * L, D, device="cuda:0")
+            ops.attention(d[:, :D], d[:, D:2 * D], d[:, 2 * D:], out, L, nseq, heads, bias=b.cuda() if bias else None,
+                          biasvar=var.cuda() if bias else None)
+            err = float((out.cpu().double() - ref).abs().max())
+            assert err < 2e-5, (L, mw, err)
+    finally:
+        lib.sgic_attention_set_max_waves(10)
+        ops.AUTOTUNE = old
