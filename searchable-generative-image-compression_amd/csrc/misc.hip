@@ -341,62 +341,104 @@ extern "C" int sgic_fake2d_transpose(const float *d_in, long in_seq_stride, floa
 
 // ------------------------------------------------------------------------------------------------
 // TiTok VQ nearest code with l2-normalised tokens and codebook (titok/quantizer.py:46-61):
-// d = |z|^2 + |e|^2 - 2 z.e ; argmin (first minimum).  One wave per token, codes strided over lanes.
+// d = |z|^2 + |e|^2 - 2 z.e ; argmin (first minimum).  Codes strided over lanes.
 // ------------------------------------------------------------------------------------------------
+// VQ_TPW tokens per workgroup, codes strided over its 256 threads: a thread normalises each of its codes ONCE and scores
+// it against those tokens (their normalised vectors sit in LDS and are read as broadcasts), instead of one wave
+// re-normalising the whole codebook per token in 64 latency-bound steps.  Per (token, code) the arithmetic is
+// unchanged -- same normalisation, same d-order dot product, same dist = |z|^2 + |e|^2 - 2 z.e, first minimum wins
+// (ties resolve to the lower code index at every reduction level) -- so the indices are identical.
+#define VQ_TPW 4
 __global__ __launch_bounds__(256) void vq_argmin_kernel(const float *__restrict__ z, int ldz, const float *__restrict__ cb,
                                                         int ncodes, int dim, int M, int l2norm, int *__restrict__ idx) {
-  const int lane = threadIdx.x & 63;
-  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (m >= M) return;
-  float zv[16];
-  float zn = 0.f;
-  for (int d = 0; d < dim; d++) {
-    zv[d] = z[(long)m * ldz + d];
-    zn += zv[d] * zv[d];
-  }
-  if (l2norm) {
-    const float inv = 1.0f / fmaxf(sqrtf(zn), 1e-12f);
-    zn = 0.f;
-    for (int d = 0; d < dim; d++) {
-      zv[d] *= inv;
-      zn += zv[d] * zv[d];
+  __shared__ float s_z[VQ_TPW][17];       // [token][dim (<= 16) | |z|^2]
+  __shared__ float s_best[4][VQ_TPW];
+  __shared__ int s_besti[4][VQ_TPW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * VQ_TPW;
+  if (tid < VQ_TPW) {
+    const int m = min(m0 + tid, M - 1);
+    float zv[16];
+    float zn = 0.f;
+#pragma unroll
+    for (int d = 0; d < 16; d++) {
+      zv[d] = d < dim ? z[(long)m * ldz + d] : 0.f;
+      if (d < dim) zn += zv[d] * zv[d];
     }
+    if (l2norm) {
+      const float inv = 1.0f / fmaxf(sqrtf(zn), 1e-12f);
+      zn = 0.f;
+#pragma unroll
+      for (int d = 0; d < 16; d++) {
+        zv[d] *= inv;
+        if (d < dim) zn += zv[d] * zv[d];
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 16; d++) s_z[tid][d] = zv[d];
+    s_z[tid][16] = zn;
   }
-  float best = INFINITY;
-  int besti = 0x7fffffff;
-  for (int c = lane; c < ncodes; c += 64) {
+  __syncthreads();
+  float best[VQ_TPW];
+  int besti[VQ_TPW];
+#pragma unroll
+  for (int t = 0; t < VQ_TPW; t++) best[t] = INFINITY, besti[t] = 0x7fffffff;
+  for (int c = tid; c < ncodes; c += 256) {
     float ev[16];
     float en = 0.f;
-    for (int d = 0; d < dim; d++) {
-      ev[d] = cb[(long)c * dim + d];
-      en += ev[d] * ev[d];
+#pragma unroll
+    for (int d = 0; d < 16; d++) {
+      ev[d] = d < dim ? cb[(long)c * dim + d] : 0.f;
+      if (d < dim) en += ev[d] * ev[d];
     }
     if (l2norm) {
       const float inv = 1.0f / fmaxf(sqrtf(en), 1e-12f);
       en = 0.f;
-      for (int d = 0; d < dim; d++) {
+#pragma unroll
+      for (int d = 0; d < 16; d++) {
         ev[d] *= inv;
-        en += ev[d] * ev[d];
+        if (d < dim) en += ev[d] * ev[d];
       }
     }
-    float dot = 0.f;
-    for (int d = 0; d < dim; d++) dot += zv[d] * ev[d];
-    const float dist = zn + en - 2.0f * dot;
-    if (dist < best) best = dist, besti = c;
+#pragma unroll
+    for (int t = 0; t < VQ_TPW; t++) {
+      float dot = 0.f;
+#pragma unroll
+      for (int d = 0; d < 16; d++)
+        if (d < dim) dot += s_z[t][d] * ev[d];
+      const float dist = s_z[t][16] + en - 2.0f * dot;
+      if (dist < best[t]) best[t] = dist, besti[t] = c;   // c ascends per thread: strict '<' keeps the first minimum
+    }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ob = __shfl_xor(best, o);
-    const int oi = __shfl_xor(besti, o);
-    if (ob < best || (ob == best && oi < besti)) best = ob, besti = oi;
+  for (int t = 0; t < VQ_TPW; t++) {
+    float b = best[t];
+    int bi = besti[t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(b, o);
+      const int oi = __shfl_xor(bi, o);
+      if (ob < b || (ob == b && oi < bi)) b = ob, bi = oi;
+    }
+    if (lane == 0) s_best[wave][t] = b, s_besti[wave][t] = bi;
   }
-  if (lane == 0) idx[m] = besti;
+  __syncthreads();
+  if (tid < VQ_TPW && m0 + tid < M) {
+    float b = s_best[0][tid];
+    int bi = s_besti[0][tid];
+    for (int w = 1; w < 4; w++) {
+      const float ob = s_best[w][tid];
+      const int oi = s_besti[w][tid];
+      if (ob < b || (ob == b && oi < bi)) b = ob, bi = oi;
+    }
+    idx[m0 + tid] = bi;
+  }
 }
 
 extern "C" int sgic_vq_argmin(const float *d_z, int ldz, const float *d_codebook, int ncodes, int dim, int M, int l2norm,
                               int32_t *d_idx, sgic_stream_t stream) {
   SGIC_REQUIRE(d_z && d_codebook && d_idx && M > 0 && ncodes > 0 && dim > 0 && dim <= 16 && ldz >= dim, "args");
-  vq_argmin_kernel<<<cdiv(M, 4), 256, 0, to_stream(stream)>>>(d_z, ldz, d_codebook, ncodes, dim, M, l2norm, d_idx);
+  vq_argmin_kernel<<<cdiv(M, VQ_TPW), 256, 0, to_stream(stream)>>>(d_z, ldz, d_codebook, ncodes, dim, M, l2norm, d_idx);
   return sgic::check_launch("vq_argmin_kernel");
 }
 

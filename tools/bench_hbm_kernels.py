@@ -46,3 +46,9 @@ yh = torch.zeros(Bq * Hq * Hq, 128, device=dev); sym = torch.zeros(Bq, 4, 16, Hq
 rep("quant_step (B=32, 8x8x64) [launch-bound]", Bq * Hq * Hq * 16 * (3 * 4 + 4 + 4), timeit(lambda: ops.quant_step(y, sm, sm[:, 64:], 128, yh, 128, Bq, Hq, Hq, 64, 1, 0.12, sym, idx)))
 x = torch.rand(32, 3, 256, 256, device=dev) * 2 - 1
 rep("im2col_patch 16x16 (+x*0.5+0.5)", 2 * x.numel() * 4, timeit(lambda: ops.im2col_patch(x, 16, 0.5, 0.5, tile16=True)))
+
+# VQ nearest-code search (1024 tokens x 4096 codes x 12 dims at the bench batch; 32 tokens for a single image)
+cbk = torch.randn(4096, 12, device=dev)
+for ntok in (1024, 32):
+    zt = torch.randn(ntok, 12, device=dev)
+    rep(f"vq_argmin {ntok} tokens x 4096 codes", ntok * 4096 * 12 * 4, timeit(lambda: ops.vq_argmin(zt, cbk, l2norm=True)))
