@@ -12,11 +12,14 @@ import torch
 torch.set_grad_enabled(False)
 
 
-def save_png(x_chw_01, path):
+def to_u8_hwc(x_chw_01):
     """torchvision.utils.save_image semantics for one image: mul(255).add_(0.5).clamp_(0,255) -> u8 (decompress.py:114)"""
+    return x_chw_01.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to("cpu", torch.uint8).numpy()
+
+
+def save_png(x_chw_01, path):
     from PIL import Image
-    a = x_chw_01.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to("cpu", torch.uint8).numpy()
-    Image.fromarray(a).save(path)
+    Image.fromarray(to_u8_hwc(x_chw_01)).save(path)
 
 
 def main(argv=None):
@@ -54,16 +57,24 @@ def main(argv=None):
     groups = {}
     for i, (_, enc, _) in enumerate(items):
         groups.setdefault(tuple(int(v) for v in enc["img_shape"]), []).append(i)
-    for shape, idxs in groups.items():
-        for s in range(0, len(idxs), args.batch_size):
-            chunk = idxs[s:s + args.batch_size]
-            x_hat = model.decode_batch([items[i][1] for i in chunk])
-            for j, i in enumerate(chunk):
-                fp, _, header = items[i]
-                pl, pr, pt, pb = header.get("padding", [0, 0, 0, 0])
-                H, Wd = x_hat.shape[2] - pt - pb, x_hat.shape[3] - pl - pr       # negative-pad crop (decompress.py:110-112)
-                img = x_hat[j, :, pt:pt + H, pl:pl + Wd].clamp(-1, 1) * 0.5 + 0.5
-                save_png(img, os.path.join(out_dir, os.path.splitext(os.path.basename(fp))[0] + ".png"))
+    # PNG encoding (zlib, releases the GIL) runs on a thread pool underneath the next batch's GPU decode
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        pending = []
+        for shape, idxs in groups.items():
+            for s in range(0, len(idxs), args.batch_size):
+                chunk = idxs[s:s + args.batch_size]
+                x_hat = model.decode_batch([items[i][1] for i in chunk])
+                for j, i in enumerate(chunk):
+                    fp, _, header = items[i]
+                    pl, pr, pt, pb = header.get("padding", [0, 0, 0, 0])
+                    H, Wd = x_hat.shape[2] - pt - pb, x_hat.shape[3] - pl - pr   # negative-pad crop (decompress.py:110-112)
+                    a = to_u8_hwc(x_hat[j, :, pt:pt + H, pl:pl + Wd].clamp(-1, 1) * 0.5 + 0.5)
+                    path = os.path.join(out_dir, os.path.splitext(os.path.basename(fp))[0] + ".png")
+                    pending.append(pool.submit(lambda arr, p: Image.fromarray(arr).save(p), a, path))
+        for f in pending:
+            f.result()
     return 0
 
 
