@@ -221,6 +221,11 @@ int sgic_nhwc3_to_nchw_clamp(const float *d_in, int ld, int B, int H, int W, flo
  * (nq, n) = sgic_gemm_f32(queries, database) and is consumed (taken entries become -inf). */
 int sgic_topk_rows(float *d_scores, int nq, int n, int k, float *d_out_scores, int32_t *d_out_idx, sgic_stream_t stream);
 
+/* F.pad(x, (pl, pr, pt, pb), mode="replicate") on (BC, H, W) fp32 planes -> (BC, H+pt+pb, W+pl+pr)
+ * (compress.py:258-261: every image is padded to a multiple of 256 before the encoder). */
+int sgic_pad_replicate(const float *d_in, float *d_out, int BC, int H, int W, int pl, int pr, int pt, int pb,
+                       sgic_stream_t stream);
+
 /* CLIP text tower front end: out[b*L+l,:] = table[ids[b,l],:] + pos[l,:] (open_clip CLIP.encode_text, reached from
  * search.py:93-97; ids outside [0,vocab) are clamped).  D multiple of 4. */
 int sgic_embed_tokens(const int32_t *d_ids, const float *d_table, const float *d_pos, float *d_out, int B, int L, int D,

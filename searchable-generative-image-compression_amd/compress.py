@@ -104,6 +104,7 @@ def main(argv=None):
     for i, (p, im) in enumerate(imgs):
         groups.setdefault(tuple(im.shape[1:]), []).append(i)
     vecs = np.zeros((len(mine), ccfg.embed_dim), dtype=np.float32)
+    from . import ops
     from .pipeline import CompressPipeline
     pipe = CompressPipeline(model, clipc, dev, want_unit=True)
 
@@ -132,7 +133,7 @@ def main(argv=None):
         for s in range(0, len(idxs), args.batch_size):
             chunk = idxs[s:s + args.batch_size]
             x = torch.stack([imgs[i][1] for i in chunk]).to(dev)
-            xp = torch.nn.functional.pad(x, (pl, pr, pt, pb), mode="replicate").contiguous()   # data movement only
+            xp = ops.pad_replicate(x.contiguous(), pl, pr, pt, pb)                               # compress.py:258-261
             h = pipe.submit(xp, clip_hw=(H, Wd))     # CLIP sees the UNPADDED top-left H x W region (compress.py:266)
             if pending is not None:
                 write_out(pending)

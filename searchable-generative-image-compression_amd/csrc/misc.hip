@@ -609,3 +609,28 @@ extern "C" int sgic_gather_eot_rows(const int *d_ids, const float *d_x, int ldx,
   gather_eot_rows_kernel<<<B, 64, 0, to_stream(stream)>>>(d_ids, d_x, ldx, d_out, L, D);
   return sgic::check_launch("gather_eot_rows_kernel");
 }
+
+// ------------------------------------------------------------------------------------------------
+// F.pad(x, (pl, pr, pt, pb), mode="replicate") on NCHW fp32 (compress.py:258-261: pad every image to a multiple of
+// 256 on the right / bottom before the encoder).  Pure data movement: out[b,c,y,x] = in[b,c,clamp(y-pt),clamp(x-pl)].
+// ------------------------------------------------------------------------------------------------
+__global__ void pad_replicate_kernel(const float *__restrict__ in, float *__restrict__ out, int BC, int H, int W, int pl,
+                                     int pt, int OH, int OW) {
+  const long total = (long)BC * OH * OW;
+  GRID_STRIDE(i, total) {
+    const int ox = (int)(i % OW);
+    long t = i / OW;
+    const int oy = (int)(t % OH);
+    const long bc = t / OH;
+    const int sy = min(max(oy - pt, 0), H - 1), sx = min(max(ox - pl, 0), W - 1);
+    out[i] = in[(bc * H + sy) * W + sx];
+  }
+}
+
+extern "C" int sgic_pad_replicate(const float *d_in, float *d_out, int BC, int H, int W, int pl, int pr, int pt, int pb,
+                                  sgic_stream_t stream) {
+  SGIC_REQUIRE(d_in && d_out && d_in != d_out && BC > 0 && H > 0 && W > 0 && pl >= 0 && pr >= 0 && pt >= 0 && pb >= 0, "args");
+  const int OH = H + pt + pb, OW = W + pl + pr;
+  pad_replicate_kernel<<<ew_grid((long)BC * OH * OW), 256, 0, to_stream(stream)>>>(d_in, d_out, BC, H, W, pl, pt, OH, OW);
+  return sgic::check_launch("pad_replicate_kernel");
+}

@@ -508,6 +508,17 @@ def unpack12_batch(streams_u8, B, n):
     return out
 
 
+def pad_replicate(x, pl, pr, pt, pb):
+    """F.pad(x, (pl, pr, pt, pb), mode="replicate") for a contiguous (B, C, H, W) fp32 device tensor"""
+    assert x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
+    B, C, H, W = x.shape
+    if pl == pr == pt == pb == 0:
+        return x
+    out = torch.empty(B, C, H + pt + pb, W + pl + pr, device=x.device, dtype=torch.float32)
+    call("sgic_pad_replicate", _p(x), _p(out), B * C, H, W, int(pl), int(pr), int(pt), int(pb))
+    return out
+
+
 def topk_rows(scores, k):
     """scores (nq, n) fp32 on device (consumed) -> (top scores (nq,k), indices (nq,k) int32)"""
     nq, n = scores.shape

@@ -97,3 +97,15 @@ def test_softmax_rows_and_topk_vs_torch():
     ref = torch.sort(s, dim=1, descending=True, stable=True)
     assert torch.equal(idx.cpu().long(), ref.indices[:, :20]) and torch.equal(val.cpu(), ref.values[:, :20])
     assert idx[3, 0].item() == 7 and idx[3, 1].item() == 100
+
+
+def test_pad_replicate_vs_torch():
+    """compress.py:258-261 (get_padding_size + F.pad replicate): bit-exact data movement"""
+    import sgic_amd  # noqa
+    from sgic_amd import ops
+    g = torch.Generator().manual_seed(1)
+    for (B, H, W, pad) in [(2, 200, 300, (0, 212, 0, 56)), (1, 256, 256, (0, 0, 0, 0)), (3, 17, 9, (2, 3, 1, 4))]:
+        x = torch.randn(B, 3, H, W, generator=g)
+        ref = torch.nn.functional.pad(x, pad, mode="replicate")
+        got = ops.pad_replicate(x.to(DEV), *pad).cpu()
+        assert got.shape == ref.shape and torch.equal(got, ref)
