@@ -30,8 +30,12 @@ class CompressPipeline:
         if key not in self._pinned:
             pin = lambda *s, dtype=torch.uint8: torch.empty(*s, dtype=dtype).pin_memory()
             self._pinned[key] = dict(hs=pin(B, cap), meta=pin(3, B, dtype=torch.int32), zs=pin(B, nz), q=pin(B, D),
-                                     unit=pin(B, D, dtype=torch.float32) if self.want_unit else None)
-        return self._pinned[key]
+                                     unit=pin(B, D, dtype=torch.float32) if self.want_unit else None, busy=False)
+        p = self._pinned[key]
+        if p["busy"]:
+            raise RuntimeError("CompressPipeline is two deep: finish() the batch submitted two calls ago before submit()")
+        p["busy"] = True
+        return p
 
     def submit(self, x, clip_hw=None):
         """x (B,3,H,W) fp32 in [-1,1] on the device, H and W multiples of 256 (already padded, compress.py:258-261).
@@ -57,6 +61,7 @@ class CompressPipeline:
         """-> list of B dicts {z_bit_stream, h_bit_stream, clip_stream[, clip_unit]} (host bytes)"""
         p, B = h["p"], h["B"]
         h["ev"].synchronize()
+        p["busy"] = False
         meta = p["meta"].numpy()
         if int(np.abs(meta[2]).sum()) != 0:
             raise RuntimeError(f"rANS encode error codes {meta[2].tolist()}")
