@@ -7,65 +7,236 @@ A step = one batch of 32 device-resident fp32 images -> 32 x (z_bit_stream, h_bi
 as host byte strings.  One process per GPU (torch.distributed / RCCL), images sharded across ranks with no
 data-path collective except the all-gather of the CLIP vectors (for the FAISS index).
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
-    python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...
-Prints ONE JSON line on rank 0.
+    python bench.py                       # 1 GPU
+    python bench.py --gpus 4              # self-launching: starts 4 ranks (children of this process), rank 0 prints
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 bench.py --gpus 4
+Prints ONE JSON line on rank 0.  `--gpus N` must equal WORLD_SIZE when a launcher set it (loud failure otherwise).
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-
 GFLOP_PER_IMAGE = 366.3        # SURVEY.md §8(d): compress at 256x256 (355.3 enc + 2.16 bottleneck + 8.8 CLIP + VQ)
+GFLOP_PER_IMAGE_DEC = 654.3    # SURVEY.md §8(d): decompress at 256x256
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
-def cpu_baseline(sd, clip_sd, cfg, clip_cfg, n_images):
-    """The oracle (kind "port"): torch-CPU fp32 restatement + C rANS, B=1 loop like compress.py:248."""
+# ------------------------------------------------------------------------------------------------ launcher
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` from a plain shell: start N ranks as CHILD processes (one per GPU, env:// rendezvous
+    on 127.0.0.1) and wait for them.  This parent never touches the GPU (no HIP call, no torch.cuda call) and never
+    exec()s; rank 0's JSON line goes straight to the inherited stdout."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            r = p.poll()
+            if r is None:
+                continue
+            alive.remove(p)
+            if r != 0 and rc == 0:
+                rc = r
+                for q in alive:       # a failed rank would leave its peers blocked in the next collective
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sd, clip_sd, cfg, clip_cfg, budget_s=28.0):
+    """The oracle (kind "port": torch-CPU fp32 restatement + C rANS / Pillow-resample oracle) timed on the host cores,
+    BASELINE.md §3 protocol on a bounded sample: B=1 loop like compress.py:248 (1 warm-up + median of 5 images) and one
+    B=32 batched pass (as many images of it as the time budget allows, at least 8)."""
+    import numpy as np
+    import torch
     from oracle import orc
     from oracle import torch_ref as TR
     from sgic_amd.data import synth_images
-    # threads actually usable: the cgroup/affinity share of this process, not the host's core count
     try:
-        cores = len(os.sched_getaffinity(0))
+        cores = len(os.sched_getaffinity(0))   # the cgroup/affinity share of this process, not the host's core count
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, int(os.environ.get("SGIC_CPU_THREADS", "16"))))
     torch.set_num_threads(cores)
     t = np.load(os.path.join(ROOT, "tests", "golden", "cdf_table.npz"))
     tab = orc.Table(t["cdf"], t["cdf_length"], t["offset"])
-    x = synth_images(n_images, 256, 256, seed=99)
-    pre = torch.randn(1, 3, 224, 224)
+    x = synth_images(32, 256, 256, seed=99)
+    mean = torch.tensor(clip_cfg.mean).view(1, 3, 1, 1)
+    std = torch.tensor(clip_cfg.std).view(1, 3, 1, 1)
+    S = clip_cfg.image_size
+
+    def compress(xb):
+        """xb (b,3,256,256) -> per-image byte strings, the same stages bench's GPU step runs"""
+        z, h, _ = TR.encoder_forward(xb * 0.5 + 0.5, sd, cfg)
+        idx = TR.vq_indices(z, sd).view(xb.shape[0], -1)
+        y = TR.bottleneck_analysis(h, sd)
+        sym, ind, _, _ = TR.four_part_prior_write(y, sd, cfg.force_zero_thres)
+        sym, ind = sym.numpy().reshape(xb.shape[0], -1), ind.numpy().reshape(xb.shape[0], -1)
+        u8 = np.stack([orc.resize_bicubic_u8(xb[b].clamp(-1, 1).mul(0.5).add(0.5).mul(255).byte().numpy(), S, S)
+                       for b in range(xb.shape[0])])
+        pre = (torch.from_numpy(u8).float().div(255.0) - mean) / std      # the RESAMPLED image feeds the CLIP tower
+        unit = TR.clip_tower(pre, clip_sd, clip_cfg)
+        out = []
+        for b in range(xb.shape[0]):
+            q = np.clip(np.round((unit[b].numpy() * 0.5 + 0.5) * 255.0), 0, 255).astype(np.uint8)
+            out.append((orc.pack12(idx[b].numpy().astype(np.int16)), orc.rans_encode(sym[b], ind[b], tab), q.tobytes()))
+        return out
+
+    t_start = time.perf_counter()
     with torch.no_grad():
+        compress(x[:1])                                       # warm-up
+        t1 = []
+        for b in range(1, 6):
+            t0 = time.perf_counter()
+            compress(x[b:b + 1])
+            t1.append(time.perf_counter() - t0)
+            print(f"[cpu_baseline] B=1 image {b}: {t1[-1]:.3f}s", file=sys.stderr, flush=True)
+        b1 = 1.0 / statistics.median(t1)
+        left = budget_s - (time.perf_counter() - t_start)
+        nb = int(max(8, min(32, left * b1 * 1.3)))            # batched leg sized to the remaining budget
         t0 = time.perf_counter()
-        done = 0
-        for b in range(n_images):
-            if b > 0 and time.perf_counter() - t0 > 25.0:   # bounded sample: ~10-30 s of CPU work
-                break
-            print(f"[cpu_baseline] image {b} t={time.perf_counter() - t0:.1f}s", file=sys.stderr, flush=True)
-            xb = x[b:b + 1]
-            z, h, _ = TR.encoder_forward(xb * 0.5 + 0.5, sd, cfg)
-            idx = TR.vq_indices(z, sd)
-            orc.pack12(idx.numpy().astype(np.int16))
-            y = TR.bottleneck_analysis(h, sd)
-            sym, ind, _, _ = TR.four_part_prior_write(y, sd, cfg.force_zero_thres)
-            orc.rans_encode(sym.numpy(), ind.numpy(), tab)
-            u8 = orc.resize_bicubic_u8((xb[0].clamp(-1, 1).mul(0.5).add(0.5)).mul(255).byte().numpy(), 224, 224)
-            TR.clip_tower(pre, clip_sd, clip_cfg)
-            done += 1
-        dt = time.perf_counter() - t0
-    n_images = done
-    return {"value": round(n_images / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{n_images} images 256x256, B=1 loop, torch-CPU fp32 restatement + C rANS oracle (oracle/)"}
+        compress(x[:nb])
+        tb = time.perf_counter() - t0
+        print(f"[cpu_baseline] B={nb} batched: {tb:.3f}s", file=sys.stderr, flush=True)
+    bb = nb / tb
+    return {"value": round(max(b1, bb), 4), "unit": "images/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
+            "legs": {"b1_loop_median_of_5": round(b1, 4), f"b{nb}_batched_one_pass": round(bb, 4)},
+            "sample": f"256x256 compress (encoder + entropy + resample + CLIP): 1 warm-up + 5 single images (median) and one "
+                      f"batch of {nb}; value = the faster leg; torch-CPU fp32 restatement + C rANS oracle (oracle/), {cores} threads"}
 
 
+# ------------------------------------------------------------------------------------------------ CPU rehearsal
+def rehearse_cpu(args, world, rank):
+    """--rehearse-cpu: the launcher / rendezvous / shard / all-gather / max-over-ranks protocol of the real bench on
+    the gloo backend with NO GPU work (tests/test_bench_launcher.py; also usable on a 1-GPU box to rehearse N ranks).
+    Prints the same JSON skeleton with value = 0 and data = "rehearsal"; never a benchmark result."""
+    import torch
+    import torch.distributed as dist
+    if os.environ.get("SGIC_BENCH_FAIL_RANK") == str(rank):     # test hook: a rank that dies before the rendezvous
+        return 3
+    if world > 1:
+        dist.init_process_group(backend="gloo", init_method="env://")
+    B, D = args.batch, 512
+    gathered = torch.empty(world * B, D)
+    g = torch.Generator().manual_seed(rank)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    tg = 0.0
+    for _ in range(args.steps):
+        unit = torch.nn.functional.normalize(torch.randn(B, D, generator=g), dim=1)
+        tq = time.perf_counter()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, unit)
+            assert torch.equal(gathered[rank * B:(rank + 1) * B], unit)
+        tg += time.perf_counter() - tq
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    per_rank = [dt]
+    if world > 1:
+        tt = torch.tensor([dt, tg], dtype=torch.float64)
+        allt = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        per_rank = [float(a[0]) for a in allt]
+        dt = max(per_rank)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher rehearsal (no GPU work)", "value": 0.0, "unit": "images/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(1, args.steps) * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "rehearsal",
+                          "config": {"workload": "rendezvous + all-gather protocol only", "global_batch": world * B},
+                          "per_rank_seconds": [round(t, 4) for t in per_rank],
+                          "allgather_ms_per_step": round(tg / max(1, args.steps) * 1e3, 3)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ roofline helpers
+def by_shape_table(prof, ops, dev, top=10):
+    """per-shape roofline of the dominant kernel from the per-launch event pairs of the timed region"""
+    agg = {}
+    for fl, ms, key in prof:
+        v = agg.setdefault(key, [0.0, 0.0, 0])
+        v[0] += fl
+        v[1] += ms
+        v[2] += 1
+    total_ms = sum(v[1] for v in agg.values()) or 1.0
+    pmc = {}
+    try:   # HBM-side counter bytes per launch and shape, from the committed rocprofv3 --pmc passes (tools/pmc_by_shape.py)
+        pmc = {tuple(r["shape"]): r for r in json.load(open(os.path.join(ROOT, "profiles", "round2_pmc_gemm_by_shape.json")))["shapes"]}
+    except Exception:
+        pass
+    rows = []
+    for key, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
+        if key and key[0] == "batched":
+            _, nb, M, N, K, res, act = key
+        else:
+            nb = 1
+            M, N, K, res, act = key[:5]
+        algo = 4.0 * nb * (M * K + N * K + M * N * (2 if res else 1))
+        r = {"M": M, "N": N, "K": K, "batch": nb, "residual": bool(res), "act": act, "calls": v[2],
+             "tflops": round(v[0] / v[1] / 1e9, 1), "frac": round(v[0] / v[1] / 1e9 / PEAK_FP32_MFMA_TFLOPS, 3),
+             "share_of_gemm_time": round(v[1] / total_ms, 4), "avg_us": round(v[1] / v[2] * 1e3, 1),
+             "algorithmic_MB": round(algo / 1e6, 1), "tile_mode": ops.tile_of(key, dev)}
+        p = pmc.get((M, N, K))
+        if p:
+            r["counter_MB"] = p["counter_MB"]
+        rows.append(r)
+    return rows
+
+
+def roofline_block(prof, ops, dev, dt, steps, flops_per_step, pmc_file):
+    gemm_flops = sum(p[0] for p in prof)
+    gemm_ms = sum(p[1] for p in prof)
+    n_launch = len(prof)
+    achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    traffic = None
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
+        traffic = int((pj["hbm_fetch_MB_per_launch_x2_corrected"] + pj["hbm_write_MB_per_launch"]) * 1e6)
+    except Exception:
+        pass
+    return {"bound": "mfma", "kernel": "gemm_f32_kernel", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "traffic_unit": f"bytes per launch (rocprofv3 PMC, profiles/{pmc_file})",
+            "launches_per_step": n_launch // max(1, steps),
+            "avg_launch_us": round(gemm_ms * 1e3 / max(1, n_launch), 2),
+            "gflop_per_launch": round(gemm_flops / max(1, n_launch) / 1e9, 3),
+            "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 4),
+            "end_to_end_frac": round(flops_per_step * steps / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+            "by_shape": by_shape_table(prof, ops, dev)}
+
+
+# ------------------------------------------------------------------------------------------------ the bench
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,16 +246,28 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--small", action="store_true", help="debug: SMALL/TINY configs (not a valid bench)")
     ap.add_argument("--mode", choices=["compress", "decompress"], default="compress",
-                    help="compress = the headline metric (BASELINE.json configs[1]); decompress = configs[2]/[4] secondary line")
+                    help="compress = the headline metric (BASELINE.json configs[1]); decompress = configs[2]/[4] as the primary line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary decompress block (configs[2]) of the N=1 line")
+    ap.add_argument("--secondary-steps", type=int, default=3)
     ap.add_argument("--h2d", action="store_true", help="also copy the input batch host->device inside every step "
                     "(PCIe-inclusive rate for DESIGN.md; never the headline value)")
-    ap.add_argument("--cpu-images", type=int, default=32, help="CPU-baseline sample: images of the same workload, B=1 loop, cut off after 25 s")
+    ap.add_argument("--rehearse-cpu", action="store_true", help="launcher/rendezvous/all-gather protocol on gloo, no GPU work")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus, sys.argv[1:])     # before anything here touches the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to report a "
+              f"mislabelled n_gpus", file=sys.stderr)
+        return 2
+    if args.rehearse_cpu:
+        return rehearse_cpu(args, world, rank)
+
+    import torch
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -100,7 +283,8 @@ def main():
     from sgic_amd.data import synth_images
 
     cfg, clip_cfg = (SMALL, CLIP_TINY) if args.small else (LARGE, CLIP_B32)
-    spec = W.full_spec(cfg) if args.mode == "decompress" else W.encoder_spec(cfg) + W.codec_misc_spec(cfg) + W.bottleneck_spec(cfg)
+    want_dec = args.mode == "decompress" or (world == 1 and not args.no_secondary)
+    spec = W.full_spec(cfg) if want_dec else W.encoder_spec(cfg) + W.codec_misc_spec(cfg) + W.bottleneck_spec(cfg)
     sd = W.synth_weights(spec, seed=1234)
     clip_sd = W.synth_weights(W.clip_spec(clip_cfg), seed=4321)
     codec = Codec(sd, cfg, dev)
@@ -119,14 +303,20 @@ def main():
     # ~1 ms) runs on a side HIP stream under the CLIP tower.
     from sgic_amd.pipeline import CompressPipeline
 
+    gather_events = []
+
     def gather(unit):
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, unit)   # CLIP vectors for the FAISS index (RCCL over xGMI)
+        if world > 1:   # CLIP vectors for the FAISS index (RCCL over xGMI): the one collective of the path
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_gather_into_tensor(gathered, unit)
+            e1.record()
+            gather_events.append((e0, e1))
 
     pipe = CompressPipeline(codec, clipc, dev, on_unit=gather)
     x_host = x.cpu().pin_memory() if args.h2d else None
 
-    def enqueue(slot):
+    def enqueue():
         xin = x
         if args.h2d:
             xin = torch.empty_like(x)
@@ -137,11 +327,10 @@ def main():
         return [(d["z_bit_stream"], d["h_bit_stream"], d["clip_stream"]) for d in pipe.finish(h)]
 
     class _Pipe:
-        prev, i, last = None, 0, None
+        prev, last = None, None
 
     def step():
-        cur = enqueue(_Pipe.i & 1)
-        _Pipe.i += 1
+        cur = enqueue()
         if _Pipe.prev is not None:
             _Pipe.last = finalize(_Pipe.prev)
         _Pipe.prev = cur
@@ -153,34 +342,36 @@ def main():
             _Pipe.prev = None
         return _Pipe.last
 
-    if args.mode == "decompress":
-        encs = codec.encode_batch(x)          # outside the timed region: the bitstreams to decode
-
-        def step():   # noqa: F811  -- one batch of .c2df payloads -> reconstructed pixels (device-resident fp32)
-            x_hat = codec.decode_batch(encs)
-            return [(b"", b"", b"")] * B if x_hat is not None else None
-
-    # one untimed priming step (independent of --warmup): first sight of every GEMM / attention shape runs the
-    # per-shape tile autotuner, and lazily-built tables (Swin row maps, CLIP resize coefficients, prior cache) fill
-    if args.mode == "compress":
-        step()
-        drain()
-        for _ in range(args.warmup):
-            step()
-        out = drain()
-    else:
-        drain = lambda: None   # noqa: E731
-        step()
-        for _ in range(args.warmup):
-            out = step()
-
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def dec_step_factory():
+        encs = codec.encode_batch(x)          # outside the timed region: the bitstreams to decode
+
+        def dstep():   # one batch of .c2df payloads -> reconstructed pixels (device-resident fp32)
+            x_hat = codec.decode_batch(encs)
+            return [(b"", b"", b"")] * B if x_hat is not None else None
+        return dstep
+
+    if args.mode == "decompress":
+        step = dec_step_factory()   # noqa: F811
+        drain = lambda: None        # noqa: E731
+
+    # one untimed priming step (independent of --warmup): first sight of every GEMM / attention shape consults the
+    # per-shape tile cache or runs the autotuner, and lazily-built tables (Swin row maps, CLIP resize coefficients,
+    # prior cache) fill
+    step()
+    drain()
+    out = None
+    for _ in range(args.warmup):
+        out = step()
+    out = drain() or out
+
     # profile window: closes pending in-context tile races (no tuning inside the timed region) and times every GEMM /
     # conv launch with its own dispatch-level event pair (hipExtLaunchKernel, no extra packets on the stream)
+    gather_events.clear()
     ops.profile_begin()
     sync()
     t0 = time.perf_counter()
@@ -188,65 +379,67 @@ def main():
         out = step()
     out = drain() or out      # the last step's host work is inside the timed region too
     sync()
-    dt = time.perf_counter() - t0
+    dt_local = dt = time.perf_counter() - t0
     prof = ops.profile_end()      # [(flops, ms, shape key)] per launch of the timed region
+    gather_ms = sum(a.elapsed_time(b) for a, b in gather_events)
+    per_rank = [(dt_local, gather_ms)]
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        tt = torch.tensor([dt_local, gather_ms], device=dev, dtype=torch.float64)
+        allt = torch.empty(world, 2, device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(allt, tt)
+        per_rank = [(float(a), float(b)) for a, b in allt.cpu().tolist()]
+        dt = max(p[0] for p in per_rank)     # MAX over ranks
 
     if rank == 0:
-        gemm_flops = sum(p[0] for p in prof)
-        gemm_ms = sum(p[1] for p in prof)
-        n_launch = len(prof)
-        if os.environ.get("SGIC_BENCH_SHAPES"):   # per-shape breakdown of the dominant kernel (stderr)
-            agg = {}
-            for fl, t_, key in prof:
-                v = agg.setdefault(key, [0.0, 0.0, 0])
-                v[0] += fl; v[1] += t_; v[2] += 1
-            for key, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                tile = ops._TILE.get(key + (str(dev),))
-                print(f"[gemm] M,N,K,res,act={key} tile={tile} calls={v[2]} total_ms={v[1]:.2f} share={v[1]/gemm_ms:.3f} "
-                      f"TF={v[0]/v[1]/1e9:.1f}", file=sys.stderr)
-        achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         total_bytes = sum(len(a) + len(b) + len(c) for a, b, c in out)
-        # HBM-side bytes per GEMM launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2-corrected + WRITE_SIZE,
-        # MI355X_MICROARCH.md) committed under profiles/; PMC counters cannot be read live from inside this process.
-        traffic = None
-        pmc_file = "round1_pmc_gemm_summary.json" if args.mode == "compress" else "round1_pmc_decompress_gemm_summary.json"
-        try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
-            traffic = int((pj["hbm_fetch_MB_per_launch_x2_corrected"] + pj["hbm_write_MB_per_launch"]) * 1e6)
-        except Exception:
-            pass
+        dec_primary = args.mode == "decompress"
+        gflop = (GFLOP_PER_IMAGE_DEC if dec_primary else GFLOP_PER_IMAGE) * (S / 256.0) ** 2
         res = {
-            "metric": ("images/sec end-to-end compress (enc+entropy+CLIP) at 256x256" if args.mode == "compress" else
+            "metric": ("images/sec end-to-end compress (enc+entropy+CLIP) at 256x256" if not dec_primary else
                        f"images/sec decompress (entropy decode + hybrid decoder + generative decoder) at {S}x{S}"),
             "value": round(world * B * args.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"configs[1]: batch={B} {S}x{S} encoder+entropy+CLIP compress per GPU, "
                                     f"{'SMALL debug model' if args.small else 'TiTok ViT-L hybrid encoder + ViT-B/32 CLIP'}, synthetic weights")
-                       if args.mode == "compress" else
+                       if not dec_primary else
                        (f"configs[2]: batch={B} {S}x{S} decompress per GPU (rANS decode chain + hybrid decoder + FeatMerge + "
                         f"taming VQGAN decoder), {'SMALL debug model' if args.small else 'production architecture'}, synthetic weights"),
                        "global_batch": world * B, "bytes_per_image": round(total_bytes / B, 1)},
-            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "traffic_unit": f"bytes per launch (rocprofv3 PMC, profiles/{pmc_file})",
-                         "launches_per_step": n_launch // max(1, args.steps),
-                         "avg_launch_us": round(gemm_ms * 1e3 / max(1, n_launch), 2),
-                         "gflop_per_launch": round(gemm_flops / max(1, n_launch) / 1e9, 3),
-                         "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 4),
-                         "end_to_end_frac": round((GFLOP_PER_IMAGE if args.mode == "compress" else 654.3) * (S / 256.0) ** 2 * B *
-                                                  args.steps / dt / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)},
+            "per_rank_images_per_s": [round(B * args.steps / p[0], 2) for p in per_rank],
+            "allgather_ms_per_step": [round(p[1] / args.steps, 4) for p in per_rank],
+            "roofline": roofline_block(prof, ops, dev, dt, args.steps, gflop * 1e9 * B,
+                                       "round2_pmc_decompress_gemm_summary.json" if dec_primary else "round2_pmc_gemm_summary.json"),
         }
-        if world == 1 and not args.no_cpu_baseline and not args.small and args.mode == "compress":
-            res["cpu_baseline"] = cpu_baseline(sd, clip_sd, cfg, clip_cfg, args.cpu_images)
+        if world == 1 and not dec_primary and not args.no_secondary:
+            # secondary line (configs[2]): the decompress path on the same process, a few steps, its own profile window
+            dstep = dec_step_factory()
+            dstep()
+            dstep()
+            ops.profile_begin()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.secondary_steps):
+                dstep()
+            torch.cuda.synchronize()
+            ddt = time.perf_counter() - t0
+            dprof = ops.profile_end()
+            res["secondary"] = {"decompress": {
+                "metric": f"images/sec decompress (rANS decode chain + hybrid decoder + FeatMerge + taming VQGAN decoder) at {S}x{S}",
+                "workload": f"configs[2]: batch={B} {S}x{S} per GPU, production architecture, synthetic weights",
+                "value": round(B * args.secondary_steps / ddt, 3), "unit": "images/s", "steps": args.secondary_steps,
+                "ms_per_step": round(ddt / args.secondary_steps * 1e3, 3),
+                "roofline": roofline_block(dprof, ops, dev, ddt, args.secondary_steps,
+                                           GFLOP_PER_IMAGE_DEC * (S / 256.0) ** 2 * 1e9 * B,
+                                           "round2_pmc_decompress_gemm_summary.json")}}
+        if world == 1 and not args.no_cpu_baseline and not args.small and not dec_primary:
+            res["cpu_baseline"] = cpu_baseline(sd, clip_sd, cfg, clip_cfg)
         print(json.dumps(res), flush=True)
+    ops.save_tile_cache()
     if world > 1:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

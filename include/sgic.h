@@ -4,7 +4,8 @@
  * Every entry point is `extern "C"`, takes plain pointers + sizes (no torch / pybind types), returns
  * 0 on success or a negative SGIC_E* code, never throws, and launches on the HIP stream it is given
  * (pass NULL for the default stream).  Pointers named d_* are DEVICE pointers (HBM); everything else is
- * host memory.  Handles are thread-compatible: one handle per thread/stream.
+ * host memory.  Handles are thread-compatible: one handle per thread/stream; the library has no mutable
+ * process-global launch state (launch options travel per call in sgic_launch_opts).
  *
  * Each block below cites the reference interface (file:line under /root/reference/src) it replaces;
  * INTEGRATION.md shows the reference-side binding.
@@ -104,6 +105,35 @@ int sgic_dequant_step(const int16_t *d_sym, const float *d_means, int ld_sm, flo
 #define SGIC_ACT_TANH 3
 #define SGIC_ACT_LRELU 4 /* LeakyReLU(0.01) */
 
+/* Launch options of the GEMM-family and attention entry points.  Passed per call (NULL = defaults): the library keeps
+ * NO process-global launch state, so two threads / streams can launch with different options concurrently.
+ *   tile_mode (sgic_gemm_f32 / sgic_gemm_batched_f32 / sgic_conv3x3_f32): 0 = built-in heuristic, 1 = 128x128,
+ *     2 = 128x64 workgroup tiles (double-buffered LDS), 3 / 4 = the same tiles with a single LDS buffer (3-4 workgroups
+ *     per CU), 5..8 = 1..4 with a start-up stagger of the co-resident workgroups, 9 / 10 = MIXED: whole rounds of
+ *     128x128 tiles for the bulk of the rows + 64x64 tiles for the remaining rows in the same launch (2 / 1 LDS
+ *     buffers), 11 = persistent 128x128 (2 resident workgroups per CU walk the tile list), 12 = persistent MIXED,
+ *     13 / 14 = 64x64 tiles as their own launch (2 / 1 buffers; small-M GEMMs).  Results are bitwise identical for
+ *     every choice (the k order is fixed by K alone); the host autotuner (sgic_amd.ops) picks per shape and persists
+ *     its picks.
+ *   attn_mode (sgic_attention_f32): 0 = built-in choice, otherwise the number of 32-query-row waves per workgroup
+ *     (4..8).  Results are bitwise identical for every choice.
+ *   profiler: non-NULL and open => the launch is dispatched with its own (start, stop) event pair (hipExtLaunchKernel:
+ *     timestamps taken by the dispatch itself, no extra packets on the stream). */
+typedef struct sgic_profiler sgic_profiler;
+typedef struct sgic_launch_opts {
+  int tile_mode;
+  int attn_mode;
+  sgic_profiler *profiler;
+} sgic_launch_opts;
+
+/* Profile window for the roofline figure of bench.py.  One profiler per launching thread.  begin() opens a window,
+ * every launch that carries the profiler in its opts is timed, end() closes the window and returns the duration in
+ * milliseconds of each launch in launch order (at most cap of them; *n_out = launches seen). */
+int sgic_profiler_create(sgic_profiler **out);
+void sgic_profiler_destroy(sgic_profiler *p);
+int sgic_profiler_begin(sgic_profiler *p, int max_launches);
+int sgic_profiler_end(sgic_profiler *p, float *ms_out, int cap, int *n_out);
+
 /* C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) + R[M,N]   -- nn.Linear / 1x1 Conv2d / im2col'd convs
  * (titok/blocks.py:37-64, blocks/swin_transformer.py:30-39,86,92, models/cross_blocks.py:55-68,
  * blocks/conv_blocks.py:63-67, blocks/dcvc.py:17-23,42-43).  fp32-input MFMA (exact fp32), fixed k
@@ -112,22 +142,7 @@ int sgic_dequant_step(const int16_t *d_sym, const float *d_means, int ld_sm, flo
  * written to a token slice [:, a:b] of an (n, L, C) buffer in place (models/cross_blocks.py:87-94). */
 int sgic_gemm_f32(const float *d_A, int lda, const float *d_W, int ldw, const float *d_bias, const float *d_R,
                   int ldr, float *d_C, int ldc, int M, int N, int K, int act, int a_seg, int a_seg_stride,
-                  int c_seg, int c_seg_stride, sgic_stream_t stream);
-
-/* Tile override for the following GEMM / conv launches of this process: 0 = built-in heuristic, 1 = 128x128,
- * 2 = 128x64 workgroup tiles (double-buffered LDS), 3 / 4 = the same tiles with a single LDS buffer (3-4 workgroups per CU),
- * 5..8 = 1..4 with a start-up stagger of the co-resident workgroups (their prologue/epilogue phases then overlap a
- * partner's MFMA stream instead of each other), 9 / 10 = MIXED: whole rounds of 128x128 tiles for the bulk of the
- * rows + 64x64 tiles for the remaining rows in the same launch (2 / 1 LDS buffers).  Results are bitwise identical for every choice (the k order is fixed); the host
- * autotuner (sgic_amd.ops) uses it to pick the faster tile per GEMM shape. */
-int sgic_gemm_set_tile(int mode);
-
-/* Profile window for the roofline figure of bench.py: between begin and end every sgic_gemm_f32 / sgic_gemm_batched_f32 /
- * sgic_conv3x3_f32 launch is dispatched with its own (start, stop) event pair (hipExtLaunchKernel: the timestamps are
- * taken by the dispatch itself, no extra packets on the stream).  end() closes the window and returns the duration in
- * milliseconds of each launch in launch order (at most max_launches of them). */
-int sgic_gemm_profile_begin(int max_launches);
-int sgic_gemm_profile_end(float *ms_out, int cap, int *n_out);
+                  int c_seg, int c_seg_stride, const sgic_launch_opts *opts, sgic_stream_t stream);
 
 /* Row LayerNorm, biased variance, eps inside sqrt, optional fused SiLU (act = SGIC_ACT_SILU); rows of x
  * and y addressed through the same kind of segment map (titok/blocks.py:36,42,
@@ -143,10 +158,8 @@ int sgic_layernorm_f32(const float *d_x, int ldx, int xseg, int xseg_stride, con
  * d_biasvar (null: 0).  nn.MultiheadAttention (titok/blocks.py:50-54) is the rowmap = bias = null case. */
 int sgic_attention_f32(const float *d_q, int ldq, const float *d_k, int ldk, const float *d_v, int ldv,
                        float *d_out, int ldo, int L, int nseq, int nheads, const int32_t *d_rowmap,
-                       const float *d_bias, const int32_t *d_biasvar, float scale, sgic_stream_t stream);
-
-/* tuning knob: maximum waves (32 query rows each) per attention workgroup, 4..10 (default 10). */
-int sgic_attention_set_max_waves(int w);
+                       const float *d_bias, const int32_t *d_biasvar, float scale, const sgic_launch_opts *opts,
+                       sgic_stream_t stream);
 
 /* im2col of non-overlapping PxP patches of an NCHW image with x*mul+add fused; patch rows in plain
  * (b,gy,gx) order or 16x16-tile-major (tile16) order (codec_sq_fixbpp.py:855,119; titok/blocks.py:98-100). */
@@ -190,11 +203,13 @@ int sgic_l2norm_u8(const float *d_x, int ldx, int M, int D, float *d_unit, uint8
  * S_b = Q_b K_b^T, O_b = P_b V_b (taming/modules/diffusionmodules/model.py:168-192). */
 int sgic_gemm_batched_f32(const float *d_A, int lda, long strideA, const float *d_W, int ldw, long strideW,
                           const float *d_bias, const float *d_R, int ldr, long strideR, float *d_C, int ldc,
-                          long strideC, int M, int N, int K, int act, int batch, sgic_stream_t stream);
+                          long strideC, int M, int N, int K, int act, int batch, const sgic_launch_opts *opts,
+                          sgic_stream_t stream);
 /* 3x3/s1/p1 Conv2d as an implicit GEMM on the matrix cores over a zero-halo NHWC input [B,H+2,W+2,Cin]
  * (Cin % 32 == 0); weights [Cout][(ky,kx,cin)]; fused bias/activation/residual (model.py:38-137,436-537). */
 int sgic_conv3x3_f32(const float *d_in_halo, const float *d_W, const float *d_bias, const float *d_R, int ldr,
-                     float *d_out, int ldc, int B, int H, int W, int Cin, int Cout, int act, sgic_stream_t stream);
+                     float *d_out, int ldc, int B, int H, int W, int Cin, int Cout, int act, const sgic_launch_opts *opts,
+                     sgic_stream_t stream);
 /* GroupNorm(groups, eps) on NHWC + optional swish; output plain or into the interior of a zero-halo buffer.
  * d_ws: B*64*C*2 doubles, d_stats: B*groups*2 floats (model.py:34-35,117-131). */
 int sgic_groupnorm_nhwc(const float *d_x, const float *d_gamma, const float *d_beta, int B, int H, int W, int C,

@@ -20,6 +20,18 @@ lib.sgic_pack12_size.argtypes = [C.c_size_t]
 c_void_p, c_int, c_float, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
 
+class LaunchOpts(C.Structure):
+    """sgic_launch_opts (include/sgic.h): per-call launch options of the GEMM-family / attention entry points"""
+    _fields_ = [("tile_mode", C.c_int), ("attn_mode", C.c_int), ("profiler", C.c_void_p)]
+
+
+def launch_opts(tile_mode=0, attn_mode=0, profiler=None):
+    """-> a by-reference ctypes argument, or NULL when every field is at its default"""
+    if not tile_mode and not attn_mode and not profiler:
+        return c_void_p(0)
+    return C.byref(LaunchOpts(int(tile_mode), int(attn_mode), profiler))
+
+
 class SgicError(RuntimeError):
     pass
 
@@ -48,7 +60,7 @@ def ptr(t):
     return c_void_p(t.ctypes.data)
 
 
-_NO_STREAM = {"sgic_pmf_to_quantized_cdf", "sgic_cdf_table_create"}
+_NO_STREAM = {"sgic_pmf_to_quantized_cdf", "sgic_cdf_table_create", "sgic_profiler_create", "sgic_profiler_begin", "sgic_profiler_end"}
 
 
 def call(name, *args):

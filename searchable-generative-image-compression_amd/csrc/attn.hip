@@ -5,16 +5,30 @@
 //   * cross blocks, L=545, 12 heads                   (models/cross_blocks.py:88 via ResidualAttentionBlock)
 //   * Swin window attention, L=256 per 16x16 window, dense additive bias (relative position table +
 //     the -inf shift masks), cyclic shift folded into a row map   (blocks/swin_transformer.py:94-128)
-//   * CLIP ViT-B/32, L=50, 12 heads                   (open_clip image tower, compress.py:72)
+//   * CLIP ViT-B/32 image tower L=50 / text tower L=77 (+causal bias)   (open_clip, compress.py:72, search.py:93-97)
 //
-// One workgroup = 4 waves = 128 query rows of one (sequence, head); each wave owns 32 query rows.
-// K/V tiles of 32 keys are staged in LDS by the whole workgroup.  Per tile and wave:
-//   S^T = K . Q^T      32 x v_mfma_f32_32x32x2_f32   (A = K tile from LDS, B = Q^T kept in 32 VGPRs)
-//   online softmax     the accumulator layout puts ONE query row on each lane (col = lane&31) with 16
-//                      of its 32 keys in registers, so max/sum are 15 in-register ops + one
-//                      cross-half shuffle
-//   O^T += V^T . P^T   32 x MFMA; P^T is consumed straight from the S^T accumulator registers (the MFMA
-//                      k index only has to pair the same key on both operands), V^T from LDS
+// Work decomposition (round 2).  A *unit* is one (sequence, head); its queries are cut into 32-row blocks and the
+// (unit, row block) pairs of the whole launch form ONE flat item list.  A workgroup = 4 waves = 4 CONSECUTIVE items,
+// one per wave, so every workgroup carries four waves of identical work whatever L is (L = 289 and 545 are 9 and 17
+// row blocks -- not multiples of anything; a workgroup-per-unit mapping leaves SIMDs idle or pads with empty waves).
+// Four consecutive items touch at most two units; the K/V tiles of both are staged (LDS region 0 / 1) and each wave
+// reads the region of its own unit.  Per 32-key tile and wave:
+//   S^T = K . Q^T      32 x v_mfma_f32_32x32x2_f32   (A = K tile from LDS, B = Q^T kept in 32 VGPRs), split over two
+//                      accumulators (dims 0-31 / 32-63) so consecutive MFMAs never wait on their own result
+//   online softmax     the accumulator layout puts ONE query row on each lane (col = lane&31) with 16 of its 32
+//                      keys in registers, so max/sum are 15 in-register ops + one cross-half shuffle
+//   O^T += V^T . P^T   32 x MFMA; P^T is consumed straight from the S^T accumulator registers (the MFMA k index only
+//                      has to pair the same key on both operands), V^T from LDS
+// Staging is register-staged (global -> VGPR -> LDS) with a double-buffered LDS ring and ONE barrier per tile
+// (NBUF = 2), or a single buffer with two barriers (NBUF = 1, half the LDS, more workgroups per CU); the loads of the
+// next tile are in flight during the current tile's MFMAs, and with two units the second unit's loads reuse the same
+// registers half a tile later.
+// Ragged shapes: L % 32 in {1, 2} (289, 545) leaves one or two extra KEYS, folded in as a rank-1 VALU update instead of
+// a 97 %-padding MFMA tile, and one or two extra QUERY rows, which are computed by pure-VALU workgroups (the first
+// blocks of the same launch: they run beside the MFMA workgroups on the otherwise idle vector pipe) instead of a
+// whole padded 32-row MFMA item per unit.
+// Placement: workgroups that share units are dealt to the SAME XCD (blocks b and b+8 share an L2) in consecutive
+// dispatch slots, so K/V of a unit is fetched from HBM once and re-read from that XCD's L2.
 // q is pre-scaled by `scale` (0.125 is a power of two, so this equals scaling the scores).
 #include "common.h"
 
@@ -24,6 +38,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define AT_KT 32      // keys per tile
 #define AT_LDK 68     // padded row stride (floats) of the K tile: 272 B -> conflict-free ds_read_b128
 #define AT_LDV 64
+#define AT_TILE (AT_KT * AT_LDK + AT_KT * AT_LDV)   // floats of one unit's K+V tile (16.5 KiB)
+#define AT_RAG_MAXL 960                              // ragged-row path: q[64] + p[L] live in a wave-private 4 KiB LDS slice
+#define AT_RAG_SLICE (64 + AT_RAG_MAXL)
 
 struct AttnArgs {
   const float *q, *k, *v;  // row-strided, head h at column offset h*64
@@ -34,30 +51,127 @@ struct AttnArgs {
   const float *bias;    // [nvar][L][L] additive bias or null
   const int *biasvar;   // [nseq] variant index or null (=> variant 0)
   float scale;
-  int nwaves, qblocks;
+  int nq;        // 32-row query blocks per unit handled on the matrix cores
+  int ipw;       // items per workgroup (4, or 2 when nq == 1 so that a workgroup never spans more than 2 units)
+  int n_items;   // nseq * nheads * nq
+  int n_wgs;     // MFMA workgroups (logical)
+  int group;     // consecutive logical workgroups dealt to one XCD
+  int rag;       // ragged query rows per unit computed on the VALU (0, 1 or 2): tokens nq*32 .. L-1
+  int n_rag_wgs; // leading blocks that run the ragged-row path (4 rows per block)
+  int stagger_cycles, first_round;  // start-up stagger of co-resident workgroups (see attn_f32_kernel), 0 = off
 };
 
-// blockDim.x = 64 * a.nwaves; one workgroup covers 32*nwaves query rows of one (sequence, head); qblocks
-// workgroups cover the sequence.  The host picks nwaves so that padding waste is small (L=289 -> 1 x 10 waves,
-// L=545 -> 2 x 9, L=256 -> 1 x 8) and K/V are staged once per (sequence, head) where possible.
-__global__ __launch_bounds__(640) void attn_f32_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) float sK[AT_KT * AT_LDK];
-  __shared__ __attribute__((aligned(16))) float sV[AT_KT * AT_LDV];
+__device__ __forceinline__ long at_row(const AttnArgs &a, int seq, int tok) {
+  return a.rowmap ? (long)a.rowmap[(long)seq * a.L + tok] : (long)seq * a.L + tok;
+}
 
-  const int qblocks = a.qblocks, nthreads = blockDim.x;
-  int bid = blockIdx.x;
-  const int qb = bid % qblocks;
-  bid /= qblocks;
-  const int head = bid % a.nheads;
-  const int seq = bid / a.nheads;
+// One ragged query row on the vector pipe: scores for all L keys (lane = key mod 64), softmax across the wave, then
+// out[d = lane] = sum_key p[key] V[key][d].  K/V rows come straight from global memory (L2-hot: the MFMA workgroups of
+// the same unit stream them at the same time); q and p live in a wave-private LDS slice.
+__device__ void attn_ragged_row(const AttnArgs &a, int unit, int tok, float *wl /* AT_RAG_SLICE floats */, int lane) {
+  const int head = unit % a.nheads, seq = unit / a.nheads, hc = head * 64;
+  const long q_row = at_row(a, seq, tok);
+  float *ql = wl, *pl = wl + 64;
+  ql[lane] = a.q[q_row * a.ldq + hc + lane] * a.scale;
+  const float *bias_row = nullptr;
+  if (a.bias) bias_row = a.bias + ((long)(a.biasvar ? a.biasvar[seq] : 0) * a.L + tok) * a.L;
+  float mx = -INFINITY;
+  for (int key = lane; key < a.L; key += 64) {
+    const float *kp = a.k + at_row(a, seq, key) * a.ldk + hc;
+    float sc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; c += 4) {
+      f32x4 k4[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) k4[j] = *reinterpret_cast<const f32x4 *>(kp + (c + j) * 4);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const f32x4 q4 = *reinterpret_cast<const f32x4 *>(ql + (c + j) * 4);   // same address on every lane: broadcast
+#pragma unroll
+        for (int t = 0; t < 4; t++) sc = fmaf(k4[j][t], q4[t], sc);
+      }
+    }
+    if (bias_row) sc += bias_row[key];
+    pl[key] = sc;
+    mx = fmaxf(mx, sc);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  const float m_use = (mx == -INFINITY) ? 0.f : mx;
+  float sum = 0.f;
+  for (int key = lane; key < a.L; key += 64) {
+    const float p = __expf(pl[key] - m_use);
+    pl[key] = p;
+    sum += p;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const int Lp = (a.L + 3) & ~3;
+  if (lane < Lp - a.L) pl[a.L + lane] = 0.f;   // zero pad to a multiple of 4 keys
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes have landed (wave-private slice)
+  float acc = 0.f;
+  for (int key = 0; key < Lp; key += 4) {
+    const f32x4 p4 = *reinterpret_cast<const f32x4 *>(pl + key);
+    float vv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) vv[j] = a.v[at_row(a, seq, min(key + j, a.L - 1)) * a.ldv + hc + lane];
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc = fmaf(p4[j], vv[j], acc);
+  }
+  a.out[q_row * a.ldo + hc + lane] = acc / sum;
+}
 
+// LDS: NBUF x UP regions of one (K tile | V tile); UP = units a workgroup can span (1 when nq % ipw == 0, else 2).
+static_assert(4 * AT_RAG_SLICE <= AT_TILE, "ragged-row slices must fit the smallest LDS configuration");
+
+template <int NBUF, int UP>
+__global__ __launch_bounds__(256, (NBUF * UP >= 4) ? 2 : 3) void attn_f32_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[NBUF * UP * AT_TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  int p = blockIdx.x;
+  if (p < a.n_rag_wgs) {  // ---- ragged query rows on the VALU ----
+    const int it = p * 4 + wave, n_units = a.nseq * a.nheads;
+    if (it < n_units * a.rag) attn_ragged_row(a, it / a.rag, a.nq * 32 + it % a.rag, smem + wave * AT_RAG_SLICE, lane);
+    return;
+  }
+  p -= a.n_rag_wgs;
+  // XCD-aware order: physical block p runs on XCD p % 8; logical workgroups [g*group, (g+1)*group) share units and are
+  // dealt to one XCD in consecutive slots
+  const int wg = (((p >> 3) / a.group) * 8 + (p & 7)) * a.group + (p >> 3) % a.group;
+  if (wg >= a.n_wgs) return;
+
+  // Start-up stagger.  A launch is short (tens of microseconds) and every workgroup of the first dispatch round starts
+  // at the same instant, so the 2-3 workgroups sharing a CU would run in lock step: all in their Q / first-tile loads
+  // together, all in their MFMA phases together, all storing together -- the matrix pipe idles through both memory
+  // phases.  Delaying the workgroup in hardware wave slot s of its SIMD by s * stagger_cycles puts one workgroup's
+  // memory phases beside the others' MFMA phases.  The slot id is read from the hardware (HW_ID.wave_id), nothing is
+  // assumed about placement; it only shifts time, never results.
+  if (a.stagger_cycles > 0 && p < a.first_round) {
+    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 7u;   // HW_REG_HW_ID bits [3:0] = wave slot in the SIMD
+    const unsigned s0 = __builtin_amdgcn_readfirstlane(slot);
+    if (s0 > 0) {
+      const long long t_end = (long long)__builtin_amdgcn_s_memtime() + (long long)s0 * a.stagger_cycles;
+      while ((long long)__builtin_amdgcn_s_memtime() < t_end) __builtin_amdgcn_s_sleep(32);
+    }
+  }
+
+  const int item0 = wg * a.ipw;
+  const int uA = item0 / a.nq;
+  const int last = min(item0 + a.ipw, a.n_items) - 1;
+  const bool two = UP > 1 && (last / a.nq) != uA;            // workgroup-uniform: a second unit is present
+  const int item = item0 + wave;
+  const bool active = wave < a.ipw && item < a.n_items;      // wave-uniform
+  const int unit = active ? item / a.nq : uA;
+  const int rb = active ? item - unit * a.nq : 0;
+  const int mine = (UP > 1 && unit != uA) ? 1 : 0;           // which staged region this wave reads
+  const int head = unit % a.nheads, seq = unit / a.nheads;
+
   const int lq = lane & 31, lh = lane >> 5;
-  const int q_tok = (qb * a.nwaves + wave) * 32 + lq;  // this lane's query token
-  const bool q_ok = q_tok < a.L;
-  const bool wave_active = (qb * a.nwaves + wave) * 32 < a.L;
-  const int q_tok_c = q_ok ? q_tok : a.L - 1;
-  const long q_row = a.rowmap ? a.rowmap[(long)seq * a.L + q_tok_c] : (long)seq * a.L + q_tok_c;
+  const int q_tok = rb * 32 + lq;  // this lane's query token
+  const bool q_ok = active && q_tok < a.L;
+  const int q_tok_c = q_tok < a.L ? q_tok : a.L - 1;
+  const long q_row = at_row(a, seq, q_tok_c);
   const int hc = head * 64;
 
   // Q^T fragment: lane (q, h) holds Q[q][(2c+h)*4 + t], c=0..7, t=0..3  (pairs with the K read below)
@@ -83,64 +197,57 @@ __global__ __launch_bounds__(640) void attn_f32_kernel(AttnArgs a) {
     bias_base = a.bias + ((long)var * a.L + q_tok_c) * a.L;
   }
 
-  // K/V staging: 32 keys x 16 float4 per operand = 512 float4 each; thread t stages float4 index t (and
-  // t + nthreads if needed).  Loads are unconditional: keys past L are clamped to the last token -- their
-  // scores are forced to -inf below, so P = 0 and the (finite) clamped K/V values never contribute.
-  const int nst = (512 + nthreads - 1) / nthreads;  // 1 or 2
+  // K/V staging: 32 keys x 16 float4 per operand = 512 float4 each = 2 + 2 per thread and unit.  Loads are
+  // unconditional: keys past L are clamped to the last token -- their scores are forced to -inf below, so P = 0 and the
+  // (finite) clamped K/V values never contribute.
+  const int kr = tid >> 4, c4 = tid & 15;     // rows kr and kr + 16, 16-byte chunk c4
+  const int seqA = uA / a.nheads, hcA = (uA % a.nheads) * 64;
+  const int uB = min(uA + 1, a.nseq * a.nheads - 1);
+  const int seqB = uB / a.nheads, hcB = (uB % a.nheads) * 64;
   f32x4 rk[2], rv[2];
-  auto issue_stage = [&](int key0) {
+  auto issue_stage = [&](int key0, int sq, int hcol) {
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-      if (i < nst) {
-        const int f = tid + nthreads * i;
-        if (f < 512) {
-          const int kr = f >> 4, c4 = f & 15;
-          const int tok = min(key0 + kr, a.L - 1);
-          const long row = a.rowmap ? a.rowmap[(long)seq * a.L + tok] : (long)seq * a.L + tok;
-          rk[i] = *reinterpret_cast<const f32x4 *>(a.k + row * a.ldk + hc + c4 * 4);
-          rv[i] = *reinterpret_cast<const f32x4 *>(a.v + row * a.ldv + hc + c4 * 4);
-        }
-      }
+      const int tok = min(key0 + kr + 16 * i, a.L - 1);
+      const long row = at_row(a, sq, tok);
+      rk[i] = *reinterpret_cast<const f32x4 *>(a.k + row * a.ldk + hcol + c4 * 4);
+      rv[i] = *reinterpret_cast<const f32x4 *>(a.v + row * a.ldv + hcol + c4 * 4);
     }
   };
-  auto store_stage = [&]() {
+  auto store_stage = [&](float *region) {
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-      if (i < nst) {
-        const int f = tid + nthreads * i;
-        if (f < 512) {
-          const int kr = f >> 4, c4 = f & 15;
-          *reinterpret_cast<f32x4 *>(&sK[kr * AT_LDK + c4 * 4]) = rk[i];
-          *reinterpret_cast<f32x4 *>(&sV[kr * AT_LDV + c4 * 4]) = rv[i];
-        }
-      }
+      *reinterpret_cast<f32x4 *>(region + (kr + 16 * i) * AT_LDK + c4 * 4) = rk[i];
+      *reinterpret_cast<f32x4 *>(region + AT_KT * AT_LDK + (kr + 16 * i) * AT_LDV + c4 * 4) = rv[i];
     }
   };
+  auto region = [&](int buf, int u) { return smem + (buf * UP + u) * AT_TILE; };
 
-  // Ragged tail: L = 289 and 545 are 9 / 17 full key tiles plus ONE key.  A 32-key MFMA tile for one key is
+  // Ragged key tail: L = 289 and 545 are 9 / 17 full key tiles plus ONE key.  A 32-key MFMA tile for one key is
   // 97 % padding, so a tail of <= 2 keys is folded into the online softmax on the VALU instead (a rank-1 update).
   const int rem = a.L % AT_KT;
-  const bool tail_valu = rem > 0 && rem <= 2;
+  const bool tail_valu = rem > 0 && rem <= 2 && a.L > AT_KT;
   const int ntiles = tail_valu ? a.L / AT_KT : (a.L + AT_KT - 1) / AT_KT;
-  issue_stage(0);
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const int key0 = kt * AT_KT;
-    __syncthreads();  // previous tile fully consumed
-    store_stage();
-    __syncthreads();
-    if (kt + 1 < ntiles) issue_stage(key0 + AT_KT);  // next tile's loads fly during this tile's 64 MFMAs
-    if (!wave_active) continue;  // a wave whose 32 query rows are all padding only helps staging (wave-uniform)
 
-    // ---- S^T[key][q] = sum_d K[key][d] * Q[q][d] ----
-    f32x16 s;
+  // one tile of this wave's item: S^T, online softmax, O^T update, reading region `reg`
+  auto compute_s = [&](const float *sK, f32x16 &s) {
+    f32x16 sb;
 #pragma unroll
-    for (int e = 0; e < 16; e++) s[e] = 0.f;
+    for (int e = 0; e < 16; e++) s[e] = 0.f, sb[e] = 0.f;
 #pragma unroll
-    for (int c = 0; c < 8; c++) {
-      const f32x4 kf = *reinterpret_cast<const f32x4 *>(&sK[lq * AT_LDK + (2 * c + lh) * 4]);
+    for (int c = 0; c < 4; c++) {   // two independent accumulation chains (dims 0-31 | 32-63), interleaved
+      const f32x4 ka = *reinterpret_cast<const f32x4 *>(&sK[lq * AT_LDK + (2 * c + lh) * 4]);
+      const f32x4 kb = *reinterpret_cast<const f32x4 *>(&sK[lq * AT_LDK + (2 * (c + 4) + lh) * 4]);
 #pragma unroll
-      for (int t = 0; t < 4; t++) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t], qf[c * 4 + t], s, 0, 0, 0);
+      for (int t = 0; t < 4; t++) {
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[t], qf[c * 4 + t], s, 0, 0, 0);
+        sb = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[t], qf[(c + 4) * 4 + t], sb, 0, 0, 0);
+      }
     }
+#pragma unroll
+    for (int e = 0; e < 16; e++) s[e] += sb[e];
+  };
+  auto softmax_pv = [&](const float *sV, f32x16 &s, int key0) {
     // lane holds keys key0 + (e&3) + 8*(e>>2) + 4*lh  for its query
     if (bias_base) {
 #pragma unroll
@@ -175,7 +282,6 @@ __global__ __launch_bounds__(640) void attn_f32_kernel(AttnArgs a) {
     m_run = m_new;
 #pragma unroll
     for (int e = 0; e < 16; e++) o0[e] *= alpha, o1[e] *= alpha;
-
     // ---- O^T[d][q] += sum_key V[key][d] * P[q][key];  k-step e pairs key (e&3)+8*(e>>2)+4*lh ----
 #pragma unroll
     for (int e = 0; e < 16; e++) {
@@ -184,11 +290,82 @@ __global__ __launch_bounds__(640) void attn_f32_kernel(AttnArgs a) {
       o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[e], o0, 0, 0, 0);
       o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[e], o1, 0, 0, 0);
     }
-  }
+  };
 
-  if (tail_valu && wave_active) {
+  if constexpr (NBUF == 2) {
+    // prologue: tile 0 of both units into buffer 0, then tile 1 of unit A into the registers
+    issue_stage(0, seqA, hcA);
+    store_stage(region(0, 0));
+    if (two) {
+      issue_stage(0, seqB, hcB);
+      store_stage(region(0, UP - 1));
+    }
+    if (ntiles > 1) issue_stage(AT_KT, seqA, hcA);
+    __syncthreads();
+    for (int kt = 0; kt < ntiles; ++kt) {
+      const int cur = kt & 1, nxt = cur ^ 1, key0 = kt * AT_KT;
+      const float *reg = region(cur, mine);
+      f32x16 s;
+      if (active) compute_s(reg, s);
+      if (kt + 1 < ntiles) {   // unit A's tile kt+1 (loaded one tile ago) -> the other buffer; then the registers go to B / A's tile kt+2
+        store_stage(region(nxt, 0));
+        if (two) issue_stage(key0 + AT_KT, seqB, hcB);
+        else if (kt + 2 < ntiles) issue_stage(key0 + 2 * AT_KT, seqA, hcA);
+      }
+      if (active) softmax_pv(reg + AT_KT * AT_LDK, s, key0);
+      if (two && kt + 1 < ntiles) {
+        store_stage(region(nxt, UP - 1));
+        if (kt + 2 < ntiles) issue_stage(key0 + 2 * AT_KT, seqA, hcA);
+      }
+      // one barrier per tile: LDS traffic only (the staged global loads stay in flight across it)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  } else {
+    f32x4 rk2[2], rv2[2];   // second unit's tile: both must be written between the two barriers
+    auto issue_stage2 = [&](int key0) {
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int tok = min(key0 + kr + 16 * i, a.L - 1);
+        const long row = at_row(a, seqB, tok);
+        rk2[i] = *reinterpret_cast<const f32x4 *>(a.k + row * a.ldk + hcB + c4 * 4);
+        rv2[i] = *reinterpret_cast<const f32x4 *>(a.v + row * a.ldv + hcB + c4 * 4);
+      }
+    };
+    issue_stage(0, seqA, hcA);
+    if (two) issue_stage2(0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+      const int key0 = kt * AT_KT;
+      store_stage(region(0, 0));
+      if (two) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+          float *r1 = region(0, UP - 1);
+          *reinterpret_cast<f32x4 *>(r1 + (kr + 16 * i) * AT_LDK + c4 * 4) = rk2[i];
+          *reinterpret_cast<f32x4 *>(r1 + AT_KT * AT_LDK + (kr + 16 * i) * AT_LDV + c4 * 4) = rv2[i];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 1 < ntiles) {  // next tile's loads fly during this tile's 64 MFMAs
+        issue_stage(key0 + AT_KT, seqA, hcA);
+        if (two) issue_stage2(key0 + AT_KT);
+      }
+      if (active) {
+        const float *reg = region(0, mine);
+        f32x16 s;
+        compute_s(reg, s);
+        softmax_pv(reg + AT_KT * AT_LDK, s, key0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // tile fully consumed before the next store
+    }
+  }
+  if (!active) return;
+
+  if (tail_valu) {
     for (int key = ntiles * AT_KT; key < a.L; ++key) {
-      const long row = a.rowmap ? a.rowmap[(long)seq * a.L + key] : (long)seq * a.L + key;
+      const long row = at_row(a, seq, key);
       const float *kp = a.k + row * a.ldk + hc, *vp = a.v + row * a.ldv + hc;
       float sc = 0.f;  // this lane's half of q . k (dims (2c+lh)*4 + t), completed by the cross-half shuffle
 #pragma unroll
@@ -234,28 +411,51 @@ __global__ __launch_bounds__(640) void attn_f32_kernel(AttnArgs a) {
   }
 }
 
-static int g_attn_max_waves = 10;
-extern "C" int sgic_attention_set_max_waves(int w) {
-  if (w < 4 || w > 10) return SGIC_EINVAL;
-  g_attn_max_waves = w;
-  return SGIC_OK;
+template <typename K>
+static inline void launch_attn(K kernel, unsigned grid, hipStream_t st, const AttnArgs &a) {
+  kernel<<<grid, 256, 0, st>>>(a);
 }
 
 extern "C" int sgic_attention_f32(const float *d_q, int ldq, const float *d_k, int ldk, const float *d_v, int ldv,
                                   float *d_out, int ldo, int L, int nseq, int nheads, const int32_t *d_rowmap,
-                                  const float *d_bias, const int32_t *d_biasvar, float scale, sgic_stream_t stream) {
+                                  const float *d_bias, const int32_t *d_biasvar, float scale, const sgic_launch_opts *opts,
+                                  sgic_stream_t stream) {
   SGIC_REQUIRE(d_q && d_k && d_v && d_out && L > 0 && nseq > 0 && nheads > 0, "args");
   SGIC_REQUIRE((ldq & 3) == 0 && (ldk & 3) == 0 && (ldv & 3) == 0 && (ldo & 3) == 0, "row strides must be multiples of 4");
   SGIC_REQUIRE(ldq >= nheads * 64 && ldk >= nheads * 64 && ldv >= nheads * 64 && ldo >= nheads * 64, "head_dim is 64");
   SGIC_REQUIRE((((uintptr_t)d_q | (uintptr_t)d_k | (uintptr_t)d_v | (uintptr_t)d_out) & 15) == 0, "16-byte alignment");
   SGIC_REQUIRE(!d_bias || (L & 3) == 0, "bias needs L % 4 == 0");
-  const int rows32 = (L + 31) / 32;             // 32-row wave slices needed
-  const int mw = g_attn_max_waves;
-  const int qblocks = (rows32 + mw - 1) / mw;   // at most 10 waves (640 threads) per workgroup
-  int nwaves = (rows32 + qblocks - 1) / qblocks;
-  if (nwaves < 4) nwaves = 4;                   // >= 256 threads so the 2-slot K/V staging covers a tile
-  AttnArgs a{d_q, d_k, d_v, d_out, ldq, ldk, ldv, ldo, L, nseq, nheads, d_rowmap, d_bias, d_biasvar, scale, nwaves, qblocks};
-  const long grid = (long)nseq * nheads * qblocks;
-  attn_f32_kernel<<<(unsigned)grid, 64 * nwaves, 0, to_stream(stream)>>>(a);
+  const int mode = opts ? opts->attn_mode : 0;
+  // attn_mode: 0 = default (= 2); odd = single LDS buffer (two barriers per tile), even = double-buffered LDS (one
+  // barrier per tile); modes 3,4 / 5,6 add the start-up stagger of 4096 / 8192 cycles per hardware wave slot
+  SGIC_REQUIRE(mode >= 0 && mode <= 6, "attn_mode 0..6");
+  const long units = (long)nseq * nheads;
+  const int rem = L % 32;
+  const int rag = (rem >= 1 && rem <= 2 && L >= 64 && L <= AT_RAG_MAXL) ? rem : 0;   // ragged query rows -> VALU path
+  const int nq = rag ? L / 32 : (L + 31) / 32;
+  const int ipw = nq == 1 ? 2 : 4;
+  const long n_items = units * nq;
+  SGIC_REQUIRE(n_items < (1l << 30), "too many (sequence, head, row block) items");
+  const int n_wgs = (int)((n_items + ipw - 1) / ipw);
+  const int group = (4 * nq) / ipw;                      // workgroups that cover 4 whole units
+  const long groups = (n_wgs + group - 1) / group;
+  const long grid_mfma = ((groups + 7) / 8) * 8 * group;
+  const int n_rag_wgs = (int)((units * rag + 3) / 4);
+  const bool up2 = (nq % ipw) != 0;
+  AttnArgs a{d_q, d_k, d_v, d_out, ldq, ldk, ldv, ldo, L, nseq, nheads, d_rowmap, d_bias, d_biasvar, scale,
+             nq, ipw, (int)n_items, n_wgs, group, rag, n_rag_wgs, mode > 2 ? 4096 * ((mode - 1) / 2) : 0, 0};
+  const unsigned grid = (unsigned)(grid_mfma + n_rag_wgs);
+  hipStream_t st = to_stream(stream);
+  const bool single = (mode & 1) != 0;
+  // first dispatch round = what is resident at once: workgroups per CU (LDS / register limited) x 256 CUs
+  const int per_cu = (!single && up2) ? 2 : 3;
+  a.first_round = per_cu * 256;
+  if (up2) {
+    if (single) launch_attn(attn_f32_kernel<1, 2>, grid, st, a);
+    else launch_attn(attn_f32_kernel<2, 2>, grid, st, a);
+  } else {
+    if (single) launch_attn(attn_f32_kernel<1, 1>, grid, st, a);
+    else launch_attn(attn_f32_kernel<2, 1>, grid, st, a);
+  }
   return sgic::check_launch("attn_f32_kernel");
 }

@@ -70,6 +70,7 @@ struct sgic_cdf_table {
   int32_t *d_cdf;     // rows*cols  cdf, INT_MAX past each row's length (decoder probe)
   int32_t *d_sizes;   // rows
   int32_t *d_offsets; // rows
+  size_t dec_lds_set; // dynamic-LDS limit already raised for rans_decode_kernel on this table's device (idempotent)
 };
 
 extern "C" int sgic_cdf_table_create(const int32_t *cdf, int rows, int cols, const int32_t *sizes,
@@ -433,11 +434,13 @@ extern "C" int sgic_rans_decode_batch(const sgic_cdf_table *t, const uint8_t *d_
   // one workgroup per image: table + stream window in LDS (dynamic: 105 KB for the 256 x 103 table)
   const size_t lds = ((size_t)t->rows * t->cols + 2 * (size_t)t->rows) * sizeof(int32_t) + DEC_WIN;
   SGIC_REQUIRE(lds <= 160 * 1024, "cdf table does not fit the 160 KB LDS");
-  static size_t lds_set = 0;
-  if (lds > lds_set) {
+  // the attribute is per device; the table lives on one device, so the "already raised" note is kept in the table (no
+  // process-global state; two threads racing here both set the same value)
+  sgic_cdf_table *tm = const_cast<sgic_cdf_table *>(t);
+  if (lds > tm->dec_lds_set) {
     SGIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rans_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds));
-    lds_set = lds;
+    tm->dec_lds_set = lds;
   }
   rans_decode_kernel<<<B, 256, lds, to_stream(stream)>>>(t->d_cdf, t->d_sizes, t->d_offsets, t->rows, t->cols, d_streams,
                                                           cap, d_off, d_len, B, d_state, d_idx, n, idx_stride, d_sym_out,

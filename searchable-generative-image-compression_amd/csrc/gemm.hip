@@ -442,67 +442,80 @@ __global__ __launch_bounds__(256, (WM == 1 && WN == 1) ? 4 : (NBUF == 1 ? 3 : 2)
   }
 }
 
-static int g_stagger = 0;
-static int g_tile_override = 0;
-// 0 = heuristic; 1 = 128x128 / 2 LDS buffers, 2 = 128x64 / 2 buffers, 3 = 128x128 / 1 buffer, 4 = 128x64 / 1 buffer,
+// Launch options arrive per call (sgic_launch_opts, include/sgic.h): there is no process-global launch state.
+// tile_mode: 0 = heuristic; 1 = 128x128 / 2 LDS buffers, 2 = 128x64 / 2 buffers, 3 = 128x128 / 1 buffer, 4 = 128x64 / 1 buffer,
 // 5..8 = 1..4 with the start-up stagger, 9 = mixed 128x128 + 64x64 tail (2 buffers), 10 = mixed, 1 buffer,
 // 11 = persistent 128x128 (2 buffers, 2 workgroups per CU walk all tiles), 12 = persistent mixed,
 // 13 / 14 = 64x64 tiles as their own launch (2 / 1 buffers, 4+ workgroups per CU): small-M GEMMs (CLIP tower, bottleneck)
-extern "C" int sgic_gemm_set_tile(int mode) {
-  if (mode < 0 || mode > 14) return SGIC_EINVAL;
-  g_stagger = (mode >= 5 && mode <= 8);
-  g_tile_override = g_stagger ? mode - 4 : mode;
+#define SGIC_TILE_MODES 14
+
+// Per-launch timing without extra packets on the stream: a launch that carries a profiler goes through
+// hipExtLaunchKernel with its own (start, stop) event pair, i.e. the timestamps are taken by the dispatch itself
+// (bench.py's live roofline figure).  Bracketing each launch with hipEventRecord instead costs ~2 us of stream time
+// per event -- 1.5 % of a compress step at 360 launches.  One profiler per launching thread (not thread-safe itself).
+struct sgic_profiler {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+  int n = -1;  // -1: closed
+};
+
+extern "C" int sgic_profiler_create(sgic_profiler **out) {
+  SGIC_REQUIRE(out, "out");
+  *out = new (std::nothrow) sgic_profiler();
+  SGIC_REQUIRE(*out, "out of memory");
   return SGIC_OK;
 }
 
-// Per-launch timing without extra packets on the stream: while a profile window is open every GEMM / conv launch goes
-// through hipExtLaunchKernel with its own (start, stop) event pair, i.e. the timestamps are taken by the dispatch itself
-// (bench.py's live roofline figure).  Bracketing each launch with hipEventRecord instead costs ~2 us of stream time
-// per event -- 1.5 % of a compress step at 360 launches.
-static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
-static int g_prof_n = -1;  // -1: closed
+extern "C" void sgic_profiler_destroy(sgic_profiler *p) {
+  if (!p) return;
+  for (auto &e : p->pool) {
+    (void)hipEventDestroy(e.first);
+    (void)hipEventDestroy(e.second);
+  }
+  delete p;
+}
 
-extern "C" int sgic_gemm_profile_begin(int max_launches) {
-  SGIC_REQUIRE(max_launches > 0, "max_launches");
-  while ((int)g_prof_pool.size() < max_launches) {
+extern "C" int sgic_profiler_begin(sgic_profiler *p, int max_launches) {
+  SGIC_REQUIRE(p && max_launches > 0, "profiler / max_launches");
+  while ((int)p->pool.size() < max_launches) {
     hipEvent_t a, b;
     SGIC_HIP(hipEventCreate(&a));
     SGIC_HIP(hipEventCreate(&b));
-    g_prof_pool.emplace_back(a, b);
+    p->pool.emplace_back(a, b);
   }
-  g_prof_n = 0;
+  p->n = 0;
   return SGIC_OK;
 }
 
-// closes the window; ms_out[i] = duration of the i-th launch since sgic_gemm_profile_begin (device must be idle or the
-// events complete: the call synchronises on the last stop event)
-extern "C" int sgic_gemm_profile_end(float *ms_out, int cap, int *n_out) {
-  SGIC_REQUIRE(g_prof_n >= 0 && n_out, "no open profile window");
-  const int total = g_prof_n, n = total < cap ? total : cap;   // total <= pool size: prof_next grows the pool first
-  g_prof_n = -1;
+// closes the window; ms_out[i] = duration of the i-th launch since sgic_profiler_begin (the call synchronises on each
+// stop event)
+extern "C" int sgic_profiler_end(sgic_profiler *p, float *ms_out, int cap, int *n_out) {
+  SGIC_REQUIRE(p && p->n >= 0 && n_out, "no open profile window");
+  const int total = p->n, n = total < cap ? total : cap;   // total <= pool size: prof_next grows the pool first
+  p->n = -1;
   for (int i = 0; i < n; i++) {
-    SGIC_HIP(hipEventSynchronize(g_prof_pool[i].second));
-    SGIC_HIP(hipEventElapsedTime(&ms_out[i], g_prof_pool[i].first, g_prof_pool[i].second));
+    SGIC_HIP(hipEventSynchronize(p->pool[i].second));
+    SGIC_HIP(hipEventElapsedTime(&ms_out[i], p->pool[i].first, p->pool[i].second));
   }
   *n_out = total;  // launches seen in the window (the caller compares it with its own count)
   return SGIC_OK;
 }
 
-// next event pair of the open window (the pool grows on demand), or null when no window is open
-static const std::pair<hipEvent_t, hipEvent_t> *prof_next() {
-  if (g_prof_n < 0) return nullptr;
-  while (g_prof_n >= (int)g_prof_pool.size()) {
+// next event pair of the open window (the pool grows on demand), or null when the launch carries no open profiler
+static const std::pair<hipEvent_t, hipEvent_t> *prof_next(const sgic_launch_opts *o) {
+  sgic_profiler *p = o ? o->profiler : nullptr;
+  if (!p || p->n < 0) return nullptr;
+  while (p->n >= (int)p->pool.size()) {
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess) return nullptr;
     if (hipEventCreate(&b) != hipSuccess) return nullptr;
-    g_prof_pool.emplace_back(a, b);
+    p->pool.emplace_back(a, b);
   }
-  return &g_prof_pool[g_prof_n++];
+  return &p->pool[p->n++];
 }
 
 template <typename K>
-static inline void launch_gemm(K kernel, dim3 grid, hipStream_t st, const GemmArgs &g) {
-  if (const auto *evp = prof_next()) {
+static inline void launch_gemm(K kernel, dim3 grid, hipStream_t st, const GemmArgs &g, const sgic_launch_opts *o) {
+  if (const auto *evp = prof_next(o)) {
     const auto &ev = *evp;
     hipExtLaunchKernelGGL(kernel, grid, dim3(256), 0, st, ev.first, ev.second, 0, g);
   } else {
@@ -510,7 +523,7 @@ static inline void launch_gemm(K kernel, dim3 grid, hipStream_t st, const GemmAr
   }
 }
 
-static int gemm_launch(GemmArgs g, int batch, hipStream_t st) {
+static int gemm_launch(GemmArgs g, int batch, hipStream_t st, const sgic_launch_opts *o) {
   const int M = g.M, N = g.N, K = g.K;
   // Tile choice: 128x128 unless the 128x64 grid fills the last round of workgroups on the 256 CUs clearly
   // better (workgroups are dispatched dynamically, so the makespan is ~ceil(blocks / 256) block-times).
@@ -521,14 +534,21 @@ static int gemm_launch(GemmArgs g, int batch, hipStream_t st) {
   };
   bool narrow = N <= 64 || eff(64) > eff(128) + 0.04;
   bool single = false, mixed = false, persist = false, tiny = false;
-  if (g_tile_override) {
-    narrow = (g_tile_override == 2 || g_tile_override == 4);
-    single = (g_tile_override == 3 || g_tile_override == 4 || g_tile_override == 10 || g_tile_override == 14);
-    mixed = g_tile_override == 9 || g_tile_override == 10 || g_tile_override == 12;
-    persist = (g_tile_override == 11 || g_tile_override == 12) && batch == 1;
-    tiny = g_tile_override >= 13;
+  int tile_mode = o ? o->tile_mode : 0;
+  SGIC_REQUIRE(tile_mode >= 0 && tile_mode <= SGIC_TILE_MODES, "tile_mode");
+  const bool stagger = tile_mode >= 5 && tile_mode <= 8;
+  if (stagger) tile_mode -= 4;
+  if (tile_mode) {
+    narrow = (tile_mode == 2 || tile_mode == 4);
+    single = (tile_mode == 3 || tile_mode == 4 || tile_mode == 10 || tile_mode == 14);
+    mixed = tile_mode == 9 || tile_mode == 10 || tile_mode == 12;
+    persist = (tile_mode == 11 || tile_mode == 12) && batch == 1;
+    tiny = tile_mode >= 13;
   }
   const bool ktail = (K % BK) != 0;
+  // heuristic for under-filled grids: when the 128-row tiling leaves more than half of the 256 CUs without a workgroup,
+  // 64x64 tiles give 4x the workgroups and a 4x shorter serial MFMA chain per wave (the latency of small-M GEMMs)
+  if (!tile_mode && !ktail && batch == 1 && (long)tm128 * ((N + (narrow ? 63 : 127)) / (narrow ? 64 : 128)) < 128) tiny = true;
   if (ktail) single = mixed = persist = tiny = false;
   const int tn = narrow ? (N + 63) / 64 : (N + 127) / 128;
   g.m_split = M;
@@ -558,28 +578,28 @@ static int gemm_launch(GemmArgs g, int batch, hipStream_t st) {
     g.per_cu = per_cu;
     // one tile's MFMA time alone on a CU ~ nk * 64(32 narrow) MFMAs * 64 cycles; delay resident slot s by s/per_cu of it
     const long tile_cycles = (long)((K + BK - 1) / BK) * (narrow ? 32 : 64) * 64;
-    g.stagger_cycles = (g_stagger && !mixed && total >= 2L * per_cu * 256) ? (int)(tile_cycles / per_cu) : 0;
+    g.stagger_cycles = (stagger && !mixed && total >= 2L * per_cu * 256) ? (int)(tile_cycles / per_cu) : 0;
   }
   if (tiny) {
     grid.x = ((M + 63) / 64) * ((N + 63) / 64);
     g.big_blocks = (int)grid.x;
     g.stagger_cycles = 0;
-    if (single) launch_gemm(gemm_f32_kernel<1, 1, false, 1, false, false>, grid, st, g);
-    else launch_gemm(gemm_f32_kernel<1, 1, false, 2, false, false>, grid, st, g);
+    if (single) launch_gemm(gemm_f32_kernel<1, 1, false, 1, false, false>, grid, st, g, o);
+    else launch_gemm(gemm_f32_kernel<1, 1, false, 2, false, false>, grid, st, g, o);
   } else if (persist) {
-    if (mixed) launch_gemm(gemm_f32_kernel<2, 2, false, 2, true, true>, grid, st, g);
-    else launch_gemm(gemm_f32_kernel<2, 2, false, 2, false, true>, grid, st, g);
+    if (mixed) launch_gemm(gemm_f32_kernel<2, 2, false, 2, true, true>, grid, st, g, o);
+    else launch_gemm(gemm_f32_kernel<2, 2, false, 2, false, true>, grid, st, g, o);
   } else if (mixed) {
-    if (single) launch_gemm(gemm_f32_kernel<2, 2, false, 1, true, false>, grid, st, g);
-    else launch_gemm(gemm_f32_kernel<2, 2, false, 2, true, false>, grid, st, g);
+    if (single) launch_gemm(gemm_f32_kernel<2, 2, false, 1, true, false>, grid, st, g, o);
+    else launch_gemm(gemm_f32_kernel<2, 2, false, 2, true, false>, grid, st, g, o);
   } else if (narrow) {
-    if (ktail) launch_gemm(gemm_f32_kernel<2, 1, true, 2, false, false>, grid, st, g);
-    else if (single) launch_gemm(gemm_f32_kernel<2, 1, false, 1, false, false>, grid, st, g);
-    else launch_gemm(gemm_f32_kernel<2, 1, false, 2, false, false>, grid, st, g);
+    if (ktail) launch_gemm(gemm_f32_kernel<2, 1, true, 2, false, false>, grid, st, g, o);
+    else if (single) launch_gemm(gemm_f32_kernel<2, 1, false, 1, false, false>, grid, st, g, o);
+    else launch_gemm(gemm_f32_kernel<2, 1, false, 2, false, false>, grid, st, g, o);
   } else {
-    if (ktail) launch_gemm(gemm_f32_kernel<2, 2, true, 2, false, false>, grid, st, g);
-    else if (single) launch_gemm(gemm_f32_kernel<2, 2, false, 1, false, false>, grid, st, g);
-    else launch_gemm(gemm_f32_kernel<2, 2, false, 2, false, false>, grid, st, g);
+    if (ktail) launch_gemm(gemm_f32_kernel<2, 2, true, 2, false, false>, grid, st, g, o);
+    else if (single) launch_gemm(gemm_f32_kernel<2, 2, false, 1, false, false>, grid, st, g, o);
+    else launch_gemm(gemm_f32_kernel<2, 2, false, 2, false, false>, grid, st, g, o);
   }
   return sgic::check_launch("gemm_f32_kernel");
 }
@@ -603,7 +623,8 @@ static int vec_ok(const float *d_bias, const float *d_R, int ldr, float *d_C, in
 // C[M,N] = act(A[M,K] @ W[N,K]^T + bias) + R      (nn.Linear / 1x1 conv semantics, all fp32)
 extern "C" int sgic_gemm_f32(const float *d_A, int lda, const float *d_W, int ldw, const float *d_bias,
                              const float *d_R, int ldr, float *d_C, int ldc, int M, int N, int K, int act,
-                             int a_seg, int a_seg_stride, int c_seg, int c_seg_stride, sgic_stream_t stream) {
+                             int a_seg, int a_seg_stride, int c_seg, int c_seg_stride, const sgic_launch_opts *opts,
+                             sgic_stream_t stream) {
   int rc = gemm_check(d_A, lda, d_W, ldw, d_bias, d_R, ldr, d_C, ldc, M, N, K, act);
   if (rc) return rc;
   SGIC_REQUIRE(lda >= K, "lda");
@@ -611,20 +632,21 @@ extern "C" int sgic_gemm_f32(const float *d_A, int lda, const float *d_W, int ld
                "row segment maps");
   GemmArgs g{d_A, d_W, d_bias, d_R, d_C, M, N, K, lda, ldw, ldr, ldc, act, a_seg, a_seg_stride, c_seg, c_seg_stride,
              vec_ok(d_bias, d_R, ldr, d_C, ldc, N, 0, 0), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  return gemm_launch(g, 1, to_stream(stream));
+  return gemm_launch(g, 1, to_stream(stream), opts);
 }
 
 // batch of independent GEMMs with element strides (stride 0 = operand shared by all batches); used for the
 // single-head attention of the VQGAN AttnBlock (model.py:168-192): S_b = Q_b K_b^T, O_b = P_b V_b.
 extern "C" int sgic_gemm_batched_f32(const float *d_A, int lda, long strideA, const float *d_W, int ldw, long strideW,
                                      const float *d_bias, const float *d_R, int ldr, long strideR, float *d_C, int ldc,
-                                     long strideC, int M, int N, int K, int act, int batch, sgic_stream_t stream) {
+                                     long strideC, int M, int N, int K, int act, int batch, const sgic_launch_opts *opts,
+                                     sgic_stream_t stream) {
   int rc = gemm_check(d_A, lda, d_W, ldw, d_bias, d_R, ldr, d_C, ldc, M, N, K, act);
   if (rc) return rc;
   SGIC_REQUIRE(lda >= K && batch > 0 && batch < 65536 && (strideA & 3) == 0 && (strideW & 3) == 0, "batch/strides");
   GemmArgs g{d_A, d_W, d_bias, d_R, d_C, M, N, K, lda, ldw, ldr, ldc, act, 0, 0, 0, 0,
              vec_ok(d_bias, d_R, ldr, d_C, ldc, N, strideC, strideR), strideA, strideW, strideC, strideR, 0, 0, 0, 0, 0, 0, 0};
-  return gemm_launch(g, batch, to_stream(stream));
+  return gemm_launch(g, batch, to_stream(stream), opts);
 }
 
 // Thin-output 3x3 convolution (Cout <= 4, Cin == 128: the taming decoder's conv_out 128 -> 3, model.py:531-537).
@@ -677,7 +699,7 @@ __global__ __launch_bounds__(256) void conv3x3_thin_kernel(const float *__restri
 // out[(b,y,x), n] = act(sum_{ky,kx,c} in[b, y+ky, x+kx, c] * W[n, (ky*3+kx)*Cin + c] + bias[n]) + R
 extern "C" int sgic_conv3x3_f32(const float *d_in_halo, const float *d_W, const float *d_bias, const float *d_R, int ldr,
                                 float *d_out, int ldc, int B, int H, int W, int Cin, int Cout, int act,
-                                sgic_stream_t stream) {
+                                const sgic_launch_opts *opts, sgic_stream_t stream) {
   const long Ml = (long)B * H * W;
   SGIC_REQUIRE(Ml < (1l << 31), "too many pixels");
   const int M = (int)Ml, K = 9 * Cin;
@@ -686,7 +708,7 @@ extern "C" int sgic_conv3x3_f32(const float *d_in_halo, const float *d_W, const 
   SGIC_REQUIRE(Cin % BK == 0, "implicit-GEMM conv needs Cin % 32 == 0");
   if (Cout == 3 && Cin == 128 && !d_R) {
     const unsigned grid = (unsigned)min((Ml + 7) / 8, 256L * 32);
-    if (const auto *evp = prof_next()) {
+    if (const auto *evp = prof_next(opts)) {
       const auto &ev = *evp;
       hipExtLaunchKernelGGL(conv3x3_thin_kernel<3>, dim3(grid), dim3(256), 0, to_stream(stream), ev.first, ev.second, 0,
                             d_in_halo, d_W, d_bias, d_out, ldc, Ml, H, W, act);
@@ -697,5 +719,5 @@ extern "C" int sgic_conv3x3_f32(const float *d_in_halo, const float *d_W, const 
   }
   GemmArgs g{d_in_halo, d_W, d_bias, d_R, d_out, M, Cout, K, Cin, K, ldr, ldc, act, 0, 0, 0, 0,
              vec_ok(d_bias, d_R, ldr, d_out, ldc, Cout, 0, 0), 0, 0, 0, 0, Cin, H, W, 0, 0, 0, 0};
-  return gemm_launch(g, 1, to_stream(stream));
+  return gemm_launch(g, 1, to_stream(stream), opts);
 }

@@ -1,23 +1,36 @@
 """Thin Python wrappers over the transform kernels of libsgic (C ABI, include/sgic.h).  Tensors are torch
 CUDA tensors used purely as device-memory handles; all arithmetic happens in the HIP kernels."""
 import ctypes
+import json
+import os
 
 import torch
 
-from ._lib import call, check, lib, require_gpu
+from ._lib import call, check, launch_opts, lib, require_gpu
 
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_TANH, ACT_LRELU = 0, 1, 2, 3, 4
 
-# Optional live profiling of the dominant kernel (bench.py): when PROFILE is a list, every gemm() launch is
-# bracketed by HIP events on the launch stream and (flops, start, end) is appended.
+# Optional live profiling of the dominant kernel (bench.py): while a window is open every GEMM / conv launch carries
+# the profiler handle in its sgic_launch_opts, so its dispatch is timed by its own event pair, and (flops, shape key)
+# is appended to PROFILE.  Host-side state of the launching thread (one process per GPU, one launching thread).
 PROFILE = None
+_PROFILER = None
+
+
+def _profiler():
+    global _PROFILER
+    if _PROFILER is None:
+        h = ctypes.c_void_p(0)
+        check(lib.sgic_profiler_create(ctypes.byref(h)), "sgic_profiler_create")
+        _PROFILER = h
+    return _PROFILER
 
 
 def profile_begin(max_launches=8192):
-    """open a profile window: every GEMM / conv launch from now on is timed by its own dispatch (sgic_gemm_profile_begin)"""
+    """open a profile window: every GEMM / conv launch from now on is timed by its own dispatch (sgic_profiler_begin)"""
     global PROFILE
     finalize_autotune()
-    check(lib.sgic_gemm_profile_begin(int(max_launches)), "sgic_gemm_profile_begin")
+    check(lib.sgic_profiler_begin(_profiler(), int(max_launches)), "sgic_profiler_begin")
     PROFILE = []
 
 
@@ -29,10 +42,14 @@ def profile_end():
     recs, PROFILE = PROFILE, None
     buf = (ctypes.c_float * max(1, len(recs)))()
     n = ctypes.c_int(0)
-    check(lib.sgic_gemm_profile_end(buf, len(recs), ctypes.byref(n)), "sgic_gemm_profile_end")
+    check(lib.sgic_profiler_end(_profiler(), buf, len(recs), ctypes.byref(n)), "sgic_profiler_end")
     if n.value != len(recs):
         raise RuntimeError(f"profile window: {len(recs)} launches recorded on the host, {n.value} timed on the device")
     return [(fl, float(buf[i]), key) for i, (fl, key) in enumerate(recs)]
+
+
+def _opts(tile=0, attn=0):
+    return launch_opts(tile, attn, _PROFILER if PROFILE is not None else None)
 
 
 def _rows(t):
@@ -53,13 +70,101 @@ def empty(*shape, like=None, dtype=torch.float32, device=None):
     return torch.empty(*shape, dtype=dtype, device=like.device if like is not None else device)
 
 
-# Per-shape tile autotuning ("measure, don't guess"): the first time a GEMM / conv / attention shape is seen, every
-# launch mode of the kernel is timed with HIP events on the launch stream and the fastest is remembered.  All modes
-# give bitwise identical results (the k order is fixed), so tuning never changes an output.  AUTOTUNE = False uses
-# the built-in heuristic.  Single-threaded by design: one process per GPU, one launching thread.
+# Per-shape launch-mode autotuning ("measure, don't guess"): the first time a GEMM / conv / attention shape is seen and
+# neither the tile cache nor a neighbouring M of the same (N, K, epilogue) family knows it, every launch mode of the
+# kernel is timed with HIP events on the launch stream and the fastest is remembered.  All modes give bitwise identical
+# results (the k order is fixed), so tuning never changes an output; the mode travels PER CALL in sgic_launch_opts (the
+# library has no global launch state).  Picks persist in a JSON tile cache, so a second process -- or a new image
+# geometry whose GEMMs only differ in M -- does not race again:
+#   1. the in-tree cache  sgic_amd/tile_cache_gfx950.json  (committed; measured on an MI355X),
+#   2. the user cache     $SGIC_TILE_CACHE or ~/.cache/sgic_amd/tile_cache_gfx950.json  (read after 1, written by
+#      save_tile_cache(); bench.py and the CLI drivers call it at exit).
+# AUTOTUNE = False uses the cache / built-in heuristic only.  Single-threaded by design (one launching thread).
 AUTOTUNE = True
 TUNE_MODES = (1, 2, 3, 4, 5, 7, 9, 10, 11, 12, 13, 14)   # {128x128, 128x64} x {double, single LDS buffer}, staggered wide, mixed 128x128 + 64x64 tail, persistent (plain, mixed), 64x64
-_TILE = {}
+ATTN_MODES = (1, 2, 3, 4, 5, 6)                            # {single, double}-buffered K/V ring x start-up stagger {0, 4096, 8192} cycles
+_TILE = {}        # key -> mode (exact shapes)
+_FAMILY = {}      # key without M -> {M: mode}
+_DIRTY = False
+_INTREE_CACHE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_cache_gfx950.json")
+
+
+def _user_cache_path():
+    return os.environ.get("SGIC_TILE_CACHE") or os.path.join(os.path.expanduser("~"), ".cache", "sgic_amd", "tile_cache_gfx950.json")
+
+
+def _remember(key, mode, dirty=True):
+    global _DIRTY
+    _TILE[key] = mode
+    _FAMILY.setdefault((key[0],) + tuple(key[2:]), {})[key[1]] = mode
+    _DIRTY = _DIRTY or dirty
+
+
+def _load_tile_cache():
+    for path in (_INTREE_CACHE, _user_cache_path()):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        for k, mode in d.get("picks", {}).items():
+            parts = k.split("|")
+            key = (parts[0],) + tuple(int(x) for x in parts[1:])
+            _remember(key, int(mode), dirty=False)
+
+
+def save_tile_cache(path=None):
+    """persist the picks of this process (merged over what the file already holds); atomic replace"""
+    global _DIRTY
+    if not _DIRTY and path is None:
+        return None
+    finalize_autotune()
+    path = path or _user_cache_path()
+    picks = {}
+    try:
+        with open(path) as f:
+            picks = json.load(f).get("picks", {})
+    except (OSError, ValueError):
+        pass
+    picks.update({"|".join(str(int(x)) if not isinstance(x, str) else x for x in k): int(v) for k, v in _TILE.items()})
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "w") as f:
+            json.dump({"device": "gfx950", "format": "kind|M|...: launch mode (sgic_launch_opts)", "picks": dict(sorted(picks.items()))}, f, indent=0)
+        os.replace(tmp, path)
+    except OSError:
+        return None
+    _DIRTY = False
+    return path
+
+
+def _lookup(key):
+    """exact pick, else the pick of the nearest M (within 2x) of the same (N, K, epilogue) family, else None"""
+    m = _TILE.get(key)
+    if m is not None:
+        return m
+    fam = _FAMILY.get((key[0],) + tuple(key[2:]))
+    if fam:
+        M = key[1]
+        near = min(fam, key=lambda x: abs(x - M))
+        if M <= 2 * near and near <= 2 * M:
+            _TILE[key] = fam[near]          # not persisted: a borrowed pick, not a measurement
+            return fam[near]
+    return None
+
+
+def tile_of(key, dev=None):
+    """launch mode in use for a profile-record shape key (bench.py's by_shape table)"""
+    if key and key[0] == "batched":
+        return 0
+    if key and key[0] == "conv3x3":
+        return _TILE.get(key)
+    M, N, K, res, act = key[:5]
+    return _TILE.get(("gemm", M, N, K, int(bool(res)), act))
+
+
+_load_tile_cache()
 
 
 def _tune(key, launch):
@@ -68,20 +173,18 @@ def _tune(key, launch):
     times = {}
     for _ in range(2):
         for mode in TUNE_MODES:
-            lib.sgic_gemm_set_tile(mode)
-            launch()
+            launch(mode)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(4):
-                launch()
+                launch(mode)
             e1.record()
             e1.synchronize()
             t = e0.elapsed_time(e1)
             times[mode] = min(t, times.get(mode, t))
-    lib.sgic_gemm_set_tile(0)
     order = sorted(times, key=times.get)
     best = order[0]
-    _TILE[key] = best
+    _remember(key, best)
     # second stage, in context: the leaders of the isolated race (within 6 % of the best) are re-timed on the next real
     # occurrences of this shape, i.e. with the caches in the state the surrounding kernels leave them in
     cands = [m for m in order[:CTX_CANDS] if times[m] <= 1.06 * times[best]]
@@ -96,9 +199,9 @@ _CTX = {}
 
 def M_big(key):
     """in-context re-timing synchronises the stream once per sample: only worth it for launches of >= ~50 us"""
-    if key and key[0] == "conv3x3":
+    if key[0] == "conv3x3":
         return True
-    return 2.0 * key[0] * key[1] * key[2] >= 5e9
+    return 2.0 * key[1] * key[2] * key[3] >= 5e9
 
 
 def _ctx_launch(key, launch):
@@ -107,15 +210,13 @@ def _ctx_launch(key, launch):
     mode = c["cands"][c["i"] % len(c["cands"])]
     c["i"] += 1
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    lib.sgic_gemm_set_tile(mode)
     e0.record()
-    launch()
+    launch(mode)
     e1.record()
-    lib.sgic_gemm_set_tile(0)
     e1.synchronize()
     c["t"][mode].append(e0.elapsed_time(e1))
     if c["i"] >= len(c["cands"]) * CTX_REPS:
-        _TILE[key] = min(c["cands"], key=lambda m: min(c["t"][m]))
+        _remember(key, min(c["cands"], key=lambda m: min(c["t"][m])))
         del _CTX[key]
 
 
@@ -125,12 +226,36 @@ def finalize_autotune():
         c = _CTX.pop(key)
         done = [m for m in c["cands"] if c["t"][m]]
         if done:
-            _TILE[key] = min(done, key=lambda m: min(c["t"][m]))
+            _remember(key, min(done, key=lambda m: min(c["t"][m])))
 
 
-def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(0, 0), c_seg=(0, 0)):
+def _pick_and_launch(key, launch, big_enough, restore=None):
+    """shared tile-mode policy of gemm() / conv3x3(): cache -> family neighbour -> race (outside profile windows) -> heuristic.
+    Returns True when the launch was already done by an in-context sample."""
+    tile = 0
+    if big_enough:
+        tile = _lookup(key)
+        if tile is None:
+            if not AUTOTUNE or PROFILE is not None:
+                tile = 0      # never tune inside a profile window (its probes would take event slots): built-in heuristic
+            elif restore is not None:
+                # in-place residual GEMMs (out is residual) are not idempotent: save / restore the buffer around tuning
+                saved = restore.clone()
+                tile = _tune(key, launch)
+                restore.copy_(saved)
+            else:
+                tile = _tune(key, launch)
+        elif key in _CTX and PROFILE is None:
+            _ctx_launch(key, launch)
+            return True
+    launch(tile)
+    return False
+
+
+def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(0, 0), c_seg=(0, 0), tile=None):
     """out[M,N] = act(a[M,K] @ w[N,K]^T + bias) + residual.  a_seg/c_seg = (seg, seg_stride) row maps:
-    logical row m of A (resp. C) lives at physical row (m // seg) * seg_stride + m % seg."""
+    logical row m of A (resp. C) lives at physical row (m // seg) * seg_stride + m % seg.
+    tile: force a launch mode (tests / tools); default = cache / autotuner."""
     require_gpu()
     a, lda = _rows(a)
     w, ldw = _rows(w)
@@ -150,32 +275,18 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(
         assert residual.shape[1] == N and residual.shape[0] >= M
     if bias is not None:
         assert bias.shape == (N,) and bias.is_contiguous()
-    def launch():
-        call("sgic_gemm_f32", _p(a), lda, _p(w), ldw, _p(bias), _p(residual), ldr, _p(out), ldc, M, N, K, act,
-             a_seg[0], a_seg[1], c_seg[0], c_seg[1])
 
-    tile = 0
-    if AUTOTUNE and M * N >= (1 << 16):
-        key = (M, N, K, residual is not None, act, str(a.device))
-        tile = _TILE.get(key)
-        if tile is None and PROFILE is not None:
-            tile = 0      # never tune inside a profile window (its probes would take event slots): built-in heuristic
-        elif tile is None:
-            # in-place residual GEMMs (out is residual) are not idempotent: save / restore the buffer around tuning
-            if residual is not None and out.data_ptr() == residual.data_ptr():
-                saved = out.clone()
-                tile = _tune(key, launch)
-                out.copy_(saved)
-            else:
-                tile = _tune(key, launch)
-        elif key in _CTX and PROFILE is None:
-            _ctx_launch(key, launch)
+    def launch(mode):
+        call("sgic_gemm_f32", _p(a), lda, _p(w), ldw, _p(bias), _p(residual), ldr, _p(out), ldc, M, N, K, act,
+             a_seg[0], a_seg[1], c_seg[0], c_seg[1], _opts(tile=mode))
+
+    if tile is not None:
+        launch(tile)
+    else:
+        key = ("gemm", M, N, K, int(residual is not None), act)
+        inplace = residual is not None and out.data_ptr() == residual.data_ptr()
+        if _pick_and_launch(key, launch, M * N >= (1 << 16), restore=out if inplace else None):
             return out
-    if tile:
-        lib.sgic_gemm_set_tile(tile)
-    launch()
-    if tile:
-        lib.sgic_gemm_set_tile(0)
     if PROFILE is not None:   # the launch took the next event pair of the open profile window (profile_begin)
         PROFILE.append((2.0 * M * N * K, (M, N, K, residual is not None, act)))
     return out
@@ -196,8 +307,8 @@ def layernorm(x, gamma, beta, out=None, eps=1e-5, act=ACT_NONE, M=None, x_seg=(0
     return out
 
 
-def attention(q, k, v, out, L, nseq, nheads, rowmap=None, bias=None, biasvar=None, scale=0.125):
-    """q,k,v,out: 2-D row-strided views (rows x nheads*64)."""
+def attention(q, k, v, out, L, nseq, nheads, rowmap=None, bias=None, biasvar=None, scale=0.125, mode=None):
+    """q,k,v,out: 2-D row-strided views (rows x nheads*64).  mode: force attn_mode (tests / tools)."""
     q, ldq = _rows(q)
     k, ldk = _rows(k)
     v, ldv = _rows(v)
@@ -208,34 +319,35 @@ def attention(q, k, v, out, L, nseq, nheads, rowmap=None, bias=None, biasvar=Non
         assert bias.dim() == 3 and bias.shape[1] == L and bias.shape[2] == L and bias.is_contiguous()
     if biasvar is not None:
         assert biasvar.dtype == torch.int32 and biasvar.numel() == nseq
-    def launch():
-        call("sgic_attention_f32", _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), ldo, L, nseq, nheads, _p(rowmap), _p(bias),
-             _p(biasvar), float(scale))
 
-    # waves per workgroup (4 / 8 / 10 x 32 query rows): padding waste vs SIMD balance vs workgroups per CU depends on
-    # L (measured: L=256 and 545 want 4, L=289 wants 10) -> tuned per shape like the GEMM tiles; results are identical.
-    mw = 10
-    if AUTOTUNE:
-        key = ("attn", L, nseq, nheads, bias is not None, str(q.device))
-        mw = _TILE.get(key)
-        if mw is None:
-            best_t = None
-            for cand in (4, 8, 10):
-                lib.sgic_attention_set_max_waves(cand)
-                launch()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(3):
-                    launch()
-                e1.record()
-                e1.synchronize()
-                t = e0.elapsed_time(e1)
-                if best_t is None or t < best_t:
-                    mw, best_t = cand, t
-            _TILE[key] = mw
-    if AUTOTUNE:
-        lib.sgic_attention_set_max_waves(mw)
-    launch()
+    def launch(m):
+        call("sgic_attention_f32", _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), ldo, L, nseq, nheads, _p(rowmap), _p(bias),
+             _p(biasvar), float(scale), launch_opts(0, m, None))
+
+    # K/V ring depth (single buffer + more workgroups per CU vs double buffer + one barrier per tile) depends on L and
+    # on how many workgroups the launch has -> tuned per shape like the GEMM tiles; results are identical.
+    if mode is None:
+        mode = 0
+        if nseq * nheads * L >= 4096:
+            key = ("attn", nseq, L, nheads, int(bias is not None))
+            mode = _lookup(key)
+            if mode is None:
+                mode = 0
+                if AUTOTUNE and PROFILE is None:
+                    best_t = None
+                    for cand in ATTN_MODES:
+                        launch(cand)
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(3):
+                            launch(cand)
+                        e1.record()
+                        e1.synchronize()
+                        t = e0.elapsed_time(e1)
+                        if best_t is None or t < best_t:
+                            mode, best_t = cand, t
+                    _remember(key, mode)
+    launch(mode)
     return out
 
 
@@ -373,13 +485,13 @@ def pack12_batch(idx_i32, B, n):
 def gemm_batched(a, lda, sa, w, ldw, sw, out, ldc, sc, M, N, K, batch, bias=None, residual=None, ldr=0, sr=0, act=ACT_NONE):
     """batch of GEMMs on raw pointers/strides (elements); a, w, out, residual are tensors used as base pointers"""
     call("sgic_gemm_batched_f32", _p(a), lda, _cl(sa), _p(w), ldw, _cl(sw), _p(bias), _p(residual), ldr, _cl(sr), _p(out), ldc,
-         _cl(sc), M, N, K, act, batch)
+         _cl(sc), M, N, K, act, batch, _opts())
     if PROFILE is not None:
         PROFILE.append((2.0 * M * N * K * batch, ("batched", batch, M, N, K, residual is not None, act)))
     return out
 
 
-def conv3x3(x_halo, w, bias, B, H, W, Cin, Cout, residual=None, act=ACT_NONE, out=None):
+def conv3x3(x_halo, w, bias, B, H, W, Cin, Cout, residual=None, act=ACT_NONE, out=None, tile=None):
     """x_halo: zero-halo NHWC buffer (B, H+2, W+2, Cin); w: (Cout, 9*Cin) in (ky,kx,cin) order -> (B*H*W, Cout)"""
     assert x_halo.is_contiguous() and x_halo.numel() == B * (H + 2) * (W + 2) * Cin
     assert w.shape == (Cout, 9 * Cin) and w.is_contiguous()
@@ -389,25 +501,18 @@ def conv3x3(x_halo, w, bias, B, H, W, Cin, Cout, residual=None, act=ACT_NONE, ou
     ldr = 0
     if residual is not None:
         residual, ldr = _rows(residual)
-    def launch():
-        call("sgic_conv3x3_f32", _p(x_halo), _p(w), _p(bias), _p(residual), ldr, _p(out), ldc, B, H, W, Cin, Cout, act)
 
-    tile = 0
-    if AUTOTUNE and B * H * W * Cout >= (1 << 20):
-        key = ("conv3x3", B, H, W, Cin, Cout, residual is not None, act, str(x_halo.device))
-        tile = _TILE.get(key)
-        if tile is None and PROFILE is not None:
-            tile = 0
-        elif tile is None:
-            tile = _tune(key, launch)     # conv outputs never alias their residual: re-running is idempotent
-        elif key in _CTX and PROFILE is None:
-            _ctx_launch(key, launch)
+    def launch(mode):
+        call("sgic_conv3x3_f32", _p(x_halo), _p(w), _p(bias), _p(residual), ldr, _p(out), ldc, B, H, W, Cin, Cout, act,
+             _opts(tile=mode))
+
+    if tile is not None:
+        launch(tile)
+    else:
+        # key[1] = M = B*H*W so that a different batch of the same geometry borrows the pick (family lookup)
+        key = ("conv3x3", B * H * W, H, W, Cin, Cout, int(residual is not None), act)
+        if _pick_and_launch(key, launch, B * H * W * Cout >= (1 << 20)):   # conv outputs never alias their residual
             return out
-    if tile:
-        lib.sgic_gemm_set_tile(tile)
-    launch()
-    if tile:
-        lib.sgic_gemm_set_tile(0)
     if PROFILE is not None:   # the implicit-GEMM convolution is the same kernel: M = B*H*W, N = Cout, K = 9*Cin
         PROFILE.append((2.0 * B * H * W * Cout * 9 * Cin, (B * H * W, Cout, 9 * Cin, residual is not None, act)))
     return out

@@ -9,7 +9,6 @@ import torch
 
 import sgic_amd  # noqa
 from sgic_amd import ops
-from sgic_amd._lib import lib
 
 dev = torch.device("cuda:0")
 M, N = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (9216, 4096)
@@ -22,17 +21,15 @@ for mode in tuple(int(x) for x in os.environ.get("MODES", "1,3,2,4,5,7,11").spli
         w = torch.rand(N, K, device=dev) * 2 - 1
         out = torch.empty(M, N, device=dev)
         res = torch.rand(M, N, device=dev) if os.environ.get('RES') else None
-        lib.sgic_gemm_set_tile(mode)
         for _ in range(3):
-            ops.gemm(a, w, residual=res, out=out)
+            ops.gemm(a, w, residual=res, out=out, tile=mode)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(10):
-            ops.gemm(a, w, residual=res, out=out)
+            ops.gemm(a, w, residual=res, out=out, tile=mode)
         e1.record()
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) / 10 * 1e3)
-    lib.sgic_gemm_set_tile(0)
     sl, ic = np.polyfit(np.array(Ks[2:], dtype=np.float64), np.array(ts[2:]), 1)
     print(f"mode {mode} M={M} N={N}: " + " ".join(f"K{K}={t:.0f}us({2*M*N*K/t/1e6:.0f}TF)" for K, t in zip(Ks, ts))
           + f" | slope {2*M*N/sl/1e6:.1f} TF, intercept {ic:.1f} us = {ic/(sl*32):.1f} k-iterations", flush=True)

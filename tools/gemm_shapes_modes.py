@@ -7,7 +7,6 @@ import torch
 
 import sgic_amd  # noqa
 from sgic_amd import ops
-from sgic_amd._lib import lib
 
 dev = torch.device("cuda:0")
 ops.AUTOTUNE = False
@@ -23,17 +22,15 @@ for (M, N, K, res) in SHAPES:
     out = torch.empty(M, N, device=dev)
     line = []
     for mode in MODES:
-        lib.sgic_gemm_set_tile(mode)
         for _ in range(3):
-            ops.gemm(a, w, residual=r, out=out)
+            ops.gemm(a, w, residual=r, out=out, tile=mode)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(10):
-            ops.gemm(a, w, residual=r, out=out)
+            ops.gemm(a, w, residual=r, out=out, tile=mode)
         e1.record()
         torch.cuda.synchronize()
         t = e0.elapsed_time(e1) / 10 * 1e3
         line.append((2 * M * N * K / t / 1e6, mode))
-    lib.sgic_gemm_set_tile(0)
     best = max(line)
     print(f"({M},{N},{K},res={res}) " + " ".join(f"m{m}={tf:.0f}" for tf, m in line) + f" | best m{best[1]} {best[0]:.1f} TF", flush=True)
