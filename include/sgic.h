@@ -241,6 +241,12 @@ int sgic_topk_rows(float *d_scores, int nq, int n, int k, float *d_out_scores, i
 int sgic_pad_replicate(const float *d_in, float *d_out, int BC, int H, int W, int pl, int pr, int pt, int pb,
                        sgic_stream_t stream);
 
+/* Image ingest: decoded RGB u8 HWC (B, H, W, 3) on the device -> `transforms.ToTensor()(img) * 2.0 - 1.0` (compress.py:
+ * 151-168) -> NCHW fp32 with F.pad(mode="replicate") fused (compress.py:258-261); out is (B, 3, H+pt+pb, W+pl+pr).
+ * Bit-identical to the torch ops (one IEEE division, multiply, subtract per sample). */
+int sgic_u8hwc_to_f32chw_pad(const uint8_t *d_in, float *d_out, int B, int H, int W, int pl, int pr, int pt, int pb,
+                             sgic_stream_t stream);
+
 /* CLIP text tower front end: out[b*L+l,:] = table[ids[b,l],:] + pos[l,:] (open_clip CLIP.encode_text, reached from
  * search.py:93-97; ids outside [0,vocab) are clamped).  D multiple of 4. */
 int sgic_embed_tokens(const int32_t *d_ids, const float *d_table, const float *d_pos, float *d_out, int B, int L, int D,

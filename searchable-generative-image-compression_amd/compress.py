@@ -2,35 +2,38 @@
 """Counterpart of the reference driver src/compress.py (same flags, same outputs:
 save_dir/{bitstreams/<stem>.c2df, clip_vecs/<stem>.npy, faiss/index.faiss, faiss/ids.txt}), running the
 MI355X path.  Differences, all MI355X-native by design:
-  * images of equal padded size are batched (--batch_size, default 32) instead of B=1;
-  * multi-GPU: one process per GPU (torchrun), every rank loads its own weights (no DDP broadcast,
-    compress.py:242), takes a contiguous shard of the sorted file list, and the CLIP vectors are
+  * the shard is STREAMED: header-only size pass, bounded read-ahead of decoded u8 batches in pinned memory, u8 H2D
+    copies overlapped with the previous batch's GPU work, ToTensor / *2-1 / replicate padding on the GPU (ingest.py);
+  * images of equal size are batched (--batch_size, default 32) instead of B=1;
+  * multi-GPU: one process per GPU (torchrun or `bench.py`-style launch), every rank loads its own weights (no DDP
+    broadcast, compress.py:242), takes a contiguous shard of the sorted file list, and the CLIP vectors are
     all-gathered with RCCL instead of going through *.npy files on a shared file system (compress.py:295-306);
+    a rank that fails still reaches the collective with an error flag, so its peers exit instead of hanging;
   * without --ckpt_path / --clip_ckpt the deterministic synthetic weights are used (there is no
     checkpoint offline); a real checkpoint with the reference's state_dict keys loads unchanged.
+The last line on stdout of rank 0 is a JSON record with the CLI-level rate (files -> .c2df, decode and writes included).
 """
 import argparse
+import json
 import os
 import sys
+import time
 from glob import glob
 
 import numpy as np
 import torch
 
+from .entropy.compression_model import get_padding_size
+
 torch.set_grad_enabled(False)
 
 
-def get_padding_size(height, width, p=64):
-    """entropy/compression_model.py:13-22"""
-    new_h = (height + p - 1) // p * p
-    new_w = (width + p - 1) // p * p
-    return 0, new_w - width, 0, new_h - height
-
-
 def load_image(path):
+    """one image as the reference's Test_Dataset yields it (compress.py:158-165): CHW fp32 in [-1,1] on the host.
+    The batch driver below does not use it (it ingests u8 and converts on the GPU); search.py query-image does."""
     from PIL import Image
     a = np.array(Image.open(path).convert("RGB"), dtype=np.uint8)
-    return torch.from_numpy(a).permute(2, 0, 1).float().div(255.0) * 2.0 - 1.0   # ToTensor, *2-1 (compress.py:161-164)
+    return torch.from_numpy(a).permute(2, 0, 1).float().div(255.0) * 2.0 - 1.0
 
 
 def load_state(path, spec_fn, cfg, seed):
@@ -44,6 +47,33 @@ def load_state(path, spec_fn, cfg, seed):
     return W.synth_weights(spec_fn(cfg), seed=seed)
 
 
+def stem_of(path):
+    return os.path.splitext(os.path.basename(path))[0]
+
+
+def assemble_index(files, vecs, bit_dir, index_dir, dim):
+    """Rank-0 index assembly (compress.py:295-306).  The reference walks `sorted(glob(clip_dir/*.npy))` -- i.e. the
+    UNIQUE stems ordered by the string "<stem>.npy" -- and adds a vector for every stem whose .c2df exists, with the
+    doc id `os.path.join(bit_dir, "<stem>.c2df")`.  `vecs[i]` belongs to `files[i]`; two inputs that share a stem
+    (a.jpg, a.png) collapse to one entry like their .npy files do (the later file in sorted order wins)."""
+    from .faiss_io import FaissDB
+    by_stem = {}
+    for i, p in enumerate(files):
+        by_stem[stem_of(p)] = i
+    order = sorted(by_stem, key=lambda s: s + ".npy")
+    if not order:
+        return []
+    db = FaissDB(index_dir, dim)
+    ids = []
+    for s in order:
+        doc_id = os.path.join(bit_dir, f"{s}.c2df")
+        if os.path.exists(doc_id):
+            db.add(vecs[by_stem[s]], doc_id)
+            ids.append(doc_id)
+    db.persist()
+    return ids
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--base_config", type=str, default=None, help="accepted for CLI compatibility (architecture is fixed)")
@@ -53,20 +83,25 @@ def main(argv=None):
     ap.add_argument("--save_dir", type=str, required=True)
     ap.add_argument("--gpu_idx", type=int, default=0)
     ap.add_argument("--batch_size", type=int, default=32)
+    ap.add_argument("--workers", type=int, default=None, help="image decode threads (default: min(16, cores))")
+    ap.add_argument("--prefetch", type=int, default=3, help="decoded batches held ahead of the GPU (bounds host memory)")
     ap.add_argument("--small", action="store_true", help="SMALL/TINY test architectures")
     args = ap.parse_args(argv)
 
     import torch.distributed as dist
+    from . import ops
     from . import weights as W
     from .codec import ClipCodec, Codec
     from .config import CLIP_B32, CLIP_TINY, LARGE, SMALL
     from .dist import gather_vectors, shard_range
-    from .faiss_io import FaissDB
     from .filemaker import pack_c2df
+    from .ingest import DeviceIngest, ShardLoader
+    from .pipeline import CompressPipeline
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", init_method="env://")
         local = int(os.environ.get("LOCAL_RANK", "0"))
     else:
@@ -94,59 +129,78 @@ def main(argv=None):
     files = sorted(glob(os.path.join(args.dataset_dir, "*.*")))
     lo, hi = shard_range(len(files), rank, world)
     mine = files[lo:hi]
-    # group by original size so that a batch shares padding and CLIP resize geometry
-    # image decode on a small thread pool (PIL releases the GIL while decoding): at 300+ images/s per GPU a serial
-    # Image.open loop would be the bottleneck of the driver
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
-        imgs = list(zip(mine, pool.map(load_image, mine)))
-    groups = {}
-    for i, (p, im) in enumerate(imgs):
-        groups.setdefault(tuple(im.shape[1:]), []).append(i)
     vecs = np.zeros((len(mine), ccfg.embed_dim), dtype=np.float32)
-    from . import ops
-    from .pipeline import CompressPipeline
     pipe = CompressPipeline(model, clipc, dev, want_unit=True)
+    ingest = DeviceIngest(dev)
+    clip_meta = clipc.meta(ccfg.embed_dim)
+    failed = None
+    t_start = time.perf_counter()
 
     def write_out(job):
         """host side of one batch: .c2df container + clip vector per image (compress.py:268-291)"""
-        h, chunk, (H, Wd), pad = job
+        h, batch, pad, copied = job
+        copied.synchronize()
+        batch.release()                       # the pinned u8 buffer goes back to the decode threads
         pl, pr, pt, pb = pad
-        for j, (i, streams) in enumerate(zip(chunk, pipe.finish(h))):
-            stem = os.path.splitext(os.path.basename(imgs[i][0]))[0]
+        for j, (i, streams) in enumerate(zip(batch.indices, pipe.finish(h))):
+            stem = stem_of(mine[i])
             enc = pipe.enc_result(h, j, streams)
             enc["clip_stream"] = streams["clip_stream"]
-            enc["clip_meta"] = clipc.meta(ccfg.embed_dim)
-            header = {"version": 2, "model_id": enc["clip_meta"]["model_id"], "embed_dim": int(ccfg.embed_dim),
-                      "quant_type": "u8_symmetric_-1_1", "image_hw": [int(H), int(Wd)],
+            enc["clip_meta"] = clip_meta
+            header = {"version": 2, "model_id": clip_meta["model_id"], "embed_dim": int(ccfg.embed_dim),
+                      "quant_type": "u8_symmetric_-1_1", "image_hw": [int(batch.H), int(batch.W)],
                       "padding": [int(pl), int(pr), int(pt), int(pb)]}
             with open(os.path.join(bit_dir, f"{stem}.c2df"), "wb") as f:
                 f.write(pack_c2df(enc, header))
             np.save(os.path.join(clip_dir, f"{stem}.npy"), streams["clip_unit"])
             vecs[i] = streams["clip_unit"]
 
-    # two-deep pipeline: the GPU works on batch k+1 while the host packs and writes batch k
-    pending = None
-    for (H, Wd), idxs in groups.items():
-        pad = get_padding_size(H, Wd, p=256)
-        pl, pr, pt, pb = pad
-        for s in range(0, len(idxs), args.batch_size):
-            chunk = idxs[s:s + args.batch_size]
-            x = torch.stack([imgs[i][1] for i in chunk]).to(dev)
-            xp = ops.pad_replicate(x.contiguous(), pl, pr, pt, pb)                               # compress.py:258-261
-            h = pipe.submit(xp, clip_hw=(H, Wd))     # CLIP sees the UNPADDED top-left H x W region (compress.py:266)
+    loader = None
+    try:
+        loader = ShardLoader(mine, args.batch_size, workers=args.workers, depth=args.prefetch)
+        # two-deep pipeline: the GPU works on batch k+1 while the host packs and writes batch k, and the decode threads
+        # are already filling the pinned buffers of batches k+2 .. k+1+prefetch
+        pending = None
+        for batch in loader:
+            pad = get_padding_size(batch.H, batch.W, p=256)                    # compress.py:257
+            x, copied = ingest(batch, pad)                                     # u8 H2D + ToTensor*2-1 + replicate pad on the GPU
+            h = pipe.submit(x, clip_hw=(batch.H, batch.W))   # CLIP sees the UNPADDED top-left H x W region (compress.py:266)
             if pending is not None:
                 write_out(pending)
-            pending = (h, chunk, (H, Wd), pad)
-    if pending is not None:
-        write_out(pending)
+            pending = (h, batch, pad, copied)
+        if pending is not None:
+            write_out(pending)
+    except BaseException as e:   # noqa: BLE001 -- reported below, after the collective the peers are waiting in
+        failed = e
+    finally:
+        if loader is not None:
+            loader.close()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t_start
+
+    # every rank reaches this point, failed or not: the error flag travels first so that nobody blocks in the gather
+    if world > 1:
+        flag = torch.tensor([1.0 if failed is not None else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if float(flag.item()) > 0:
+            dist.destroy_process_group()
+            if failed is not None:
+                raise failed
+            print(f"[rank {rank}] another rank failed; exiting without writing the index", file=sys.stderr)
+            return 1
+    elif failed is not None:
+        raise failed
     allv = gather_vectors(torch.from_numpy(vecs).to(dev), len(files), rank, world).cpu().numpy()
-    if rank == 0 and len(files) > 0:
-        db = FaissDB(index_dir, ccfg.embed_dim)
-        for i, p in enumerate(files):
-            stem = os.path.splitext(os.path.basename(p))[0]
-            db.add(allv[i], os.path.join(bit_dir, f"{stem}.c2df"))
-        db.persist()
+    rate = torch.tensor([len(mine) / dt if dt > 0 else 0.0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(rate, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        assemble_index(files, allv, bit_dir, index_dir, ccfg.embed_dim)
+        print(json.dumps({"cli_images_per_s": round(float(rate.item()), 2), "images": len(files), "n_gpus": world,
+                          "seconds_rank0": round(dt, 3), "batch_size": args.batch_size,
+                          "note": "files -> .c2df: header pass, JPEG/PNG decode, H2D, encoder+entropy+CLIP, container + .npy writes"}),
+              flush=True)
+    ops.save_tile_cache()
     if world > 1:
         dist.destroy_process_group()
     return 0

@@ -42,6 +42,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define AT_RAG_MAXL 960                              // ragged-row path: q[64] + p[L] live in a wave-private 4 KiB LDS slice
 #define AT_RAG_SLICE (64 + AT_RAG_MAXL)
 
+// Diagnostic build only (tools/micro/attn_stamps.hip defines AT_STAMPS): four s_memtime stamps per wave -- start, main
+// loop entered, main loop left, stores issued -- into a buffer nothing else reads.  The product build has no stamps.
+#ifdef AT_STAMPS
+__device__ long long at_stamps[4 * (1 << 17)];   // s_memtime (shader cycles; the counter base differs between dies)
+__device__ long long at_real[2 * (1 << 17)];     // s_memrealtime at stamps 0 and 3 (100 MHz, one base for the chip)
+#define AT_STAMP(i)                                                                                   \
+  do {                                                                                                \
+    if ((threadIdx.x & 63) == 0) {                                                                    \
+      const size_t w_ = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);                                  \
+      at_stamps[w_ * 4 + (i)] = (long long)__builtin_amdgcn_s_memtime();                              \
+      if ((i) == 0 || (i) == 3) at_real[w_ * 2 + ((i) == 3)] = (long long)__builtin_amdgcn_s_memrealtime(); \
+    }                                                                                                 \
+  } while (0)
+#else
+#define AT_STAMP(i)
+#endif
+
 struct AttnArgs {
   const float *q, *k, *v;  // row-strided, head h at column offset h*64
   float *out;
@@ -156,6 +173,7 @@ __global__ __launch_bounds__(256, (NBUF * UP >= 4) ? 2 : 3) void attn_f32_kernel
     }
   }
 
+  AT_STAMP(0);
   const int item0 = wg * a.ipw;
   const int uA = item0 / a.nq;
   const int last = min(item0 + a.ipw, a.n_items) - 1;
@@ -302,6 +320,7 @@ __global__ __launch_bounds__(256, (NBUF * UP >= 4) ? 2 : 3) void attn_f32_kernel
     }
     if (ntiles > 1) issue_stage(AT_KT, seqA, hcA);
     __syncthreads();
+    AT_STAMP(1);
     for (int kt = 0; kt < ntiles; ++kt) {
       const int cur = kt & 1, nxt = cur ^ 1, key0 = kt * AT_KT;
       const float *reg = region(cur, mine);
@@ -334,6 +353,7 @@ __global__ __launch_bounds__(256, (NBUF * UP >= 4) ? 2 : 3) void attn_f32_kernel
     };
     issue_stage(0, seqA, hcA);
     if (two) issue_stage2(0);
+    AT_STAMP(1);
     for (int kt = 0; kt < ntiles; ++kt) {
       const int key0 = kt * AT_KT;
       store_stage(region(0, 0));
@@ -361,6 +381,7 @@ __global__ __launch_bounds__(256, (NBUF * UP >= 4) ? 2 : 3) void attn_f32_kernel
       __builtin_amdgcn_s_barrier();  // tile fully consumed before the next store
     }
   }
+  AT_STAMP(2);
   if (!active) return;
 
   if (tail_valu) {
@@ -409,6 +430,7 @@ __global__ __launch_bounds__(256, (NBUF * UP >= 4) ? 2 : 3) void attn_f32_kernel
       *reinterpret_cast<f32x4 *>(op + 32 + d) = w1;
     }
   }
+  AT_STAMP(3);
 }
 
 template <typename K>
@@ -426,7 +448,7 @@ extern "C" int sgic_attention_f32(const float *d_q, int ldq, const float *d_k, i
   SGIC_REQUIRE((((uintptr_t)d_q | (uintptr_t)d_k | (uintptr_t)d_v | (uintptr_t)d_out) & 15) == 0, "16-byte alignment");
   SGIC_REQUIRE(!d_bias || (L & 3) == 0, "bias needs L % 4 == 0");
   const int mode = opts ? opts->attn_mode : 0;
-  // attn_mode: 0 = default (= 2); odd = single LDS buffer (two barriers per tile), even = double-buffered LDS (one
+  // attn_mode: 0 = default (see below); odd = single LDS buffer (two barriers per tile), even = double-buffered LDS (one
   // barrier per tile); modes 3,4 / 5,6 add the start-up stagger of 4096 / 8192 cycles per hardware wave slot
   SGIC_REQUIRE(mode >= 0 && mode <= 6, "attn_mode 0..6");
   const long units = (long)nseq * nheads;
@@ -443,11 +465,16 @@ extern "C" int sgic_attention_f32(const float *d_q, int ldq, const float *d_k, i
   const int n_rag_wgs = (int)((units * rag + 3) / 4);
   const bool up2 = (nq % ipw) != 0;
   AttnArgs a{d_q, d_k, d_v, d_out, ldq, ldk, ldv, ldo, L, nseq, nheads, d_rowmap, d_bias, d_biasvar, scale,
-             nq, ipw, (int)n_items, n_wgs, group, rag, n_rag_wgs, mode > 2 ? 4096 * ((mode - 1) / 2) : 0, 0};
+             nq, ipw, (int)n_items, n_wgs, group, rag, n_rag_wgs, 0, 0};
   const unsigned grid = (unsigned)(grid_mfma + n_rag_wgs);
   hipStream_t st = to_stream(stream);
-  const bool single = (mode & 1) != 0;
+  // default (mode 0), from the round-2 measurements (tools/bench_attn.py, tools/micro/attn_stamps.hip): a single K/V buffer
+  // (3 workgroups per CU) with the 8192-cycle start-up stagger when workgroups span two units (L = 289, 545), the plain
+  // single buffer otherwise (L = 256 windows, the CLIP towers)
+  const int eff = mode ? mode : (up2 ? 5 : 1);
+  const bool single = (eff & 1) != 0;
   // first dispatch round = what is resident at once: workgroups per CU (LDS / register limited) x 256 CUs
+  a.stagger_cycles = eff > 2 ? 4096 * ((eff - 1) / 2) : 0;
   const int per_cu = (!single && up2) ? 2 : 3;
   a.first_round = per_cu * 256;
   if (up2) {

@@ -634,3 +634,34 @@ extern "C" int sgic_pad_replicate(const float *d_in, float *d_out, int BC, int H
   pad_replicate_kernel<<<ew_grid((long)BC * OH * OW), 256, 0, to_stream(stream)>>>(d_in, d_out, BC, H, W, pl, pt, OH, OW);
   return sgic::check_launch("pad_replicate_kernel");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Image ingest (compress.py:151-168 Test_Dataset + :258-261): decoded RGB u8 HWC (what PIL hands over, copied to the
+// device as bytes -- a quarter of the fp32 PCIe traffic) -> ToTensor (x / 255) -> x * 2 - 1 -> NCHW fp32, with the
+// replicate padding to a multiple of 256 fused into the same pass.  One IEEE division, one multiply, one subtract per
+// sample (this file is built with -ffp-contract=off), so the result is bit-identical to
+// `transforms.ToTensor()(img) * 2.0 - 1.0` followed by F.pad(mode="replicate").
+// ------------------------------------------------------------------------------------------------
+__global__ void u8hwc_to_f32chw_pad_kernel(const uint8_t *__restrict__ in, float *__restrict__ out, int B, int H, int W, int pl,
+                                           int pt, int OH, int OW) {
+  const long total = (long)B * 3 * OH * OW;
+  GRID_STRIDE(i, total) {
+    const int ox = (int)(i % OW);
+    long t = i / OW;
+    const int oy = (int)(t % OH);
+    t /= OH;
+    const int c = (int)(t % 3);
+    const long b = t / 3;
+    const int sy = min(max(oy - pt, 0), H - 1), sx = min(max(ox - pl, 0), W - 1);
+    const float v = (float)in[((b * H + sy) * W + sx) * 3 + c];
+    out[i] = __fdiv_rn(v, 255.0f) * 2.0f - 1.0f;
+  }
+}
+
+extern "C" int sgic_u8hwc_to_f32chw_pad(const uint8_t *d_in, float *d_out, int B, int H, int W, int pl, int pr, int pt, int pb,
+                                        sgic_stream_t stream) {
+  SGIC_REQUIRE(d_in && d_out && B > 0 && H > 0 && W > 0 && pl >= 0 && pr >= 0 && pt >= 0 && pb >= 0, "args");
+  const int OH = H + pt + pb, OW = W + pl + pr;
+  u8hwc_to_f32chw_pad_kernel<<<ew_grid((long)B * 3 * OH * OW), 256, 0, to_stream(stream)>>>(d_in, d_out, B, H, W, pl, pt, OH, OW);
+  return sgic::check_launch("u8hwc_to_f32chw_pad_kernel");
+}

@@ -1,0 +1,165 @@
+"""Streaming image ingest for the compress driver (replaces the reference's `Test_Dataset` + DataLoader,
+compress.py:151-168,211-215, and its per-image `.to(device)` at :252).
+
+The reference decodes one image per step into fp32 on 4 DataLoader workers.  At 300+ images/s per MI355X the host side
+has to be a pipeline of its own, with bounded memory whatever the corpus size:
+
+  1. header pass   -- `Image.open(path).size` reads the image header only (no pixel decode): every file of the shard
+                      gets its geometry, and consecutive files of equal geometry are cut into batches (a batch shares
+                      padding and CLIP resize geometry).  File order inside a geometry stays the sorted order.
+  2. decode        -- a thread pool (PIL releases the GIL while decoding) fills a PINNED u8 (B,H,W,3) buffer per batch.
+                      At most `depth` batches are decoded ahead of the consumer: memory is O(depth x batch), not
+                      O(shard) -- a 10 k-image shard of 1024^2 inputs costs ~100 MB per in-flight batch, not 126 GB.
+  3. H2D + convert -- the consumer copies the u8 batch to the device asynchronously on a copy stream (a quarter of the
+                      bytes of an fp32 copy) and one HIP kernel does ToTensor, *2-1, NCHW and the replicate padding
+                      (ops.u8hwc_to_f32chw_pad).  The copy of batch k+1 runs under the GPU work of batch k.
+"""
+import os
+import queue
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+
+
+def image_size(path):
+    """(H, W) from the file header; no pixel data is decoded"""
+    from PIL import Image
+    with Image.open(path) as im:
+        w, h = im.size
+    return h, w
+
+
+def decode_rgb_u8(path, out_hw3):
+    """`Image.open(path).convert('RGB')` (compress.py:160) decoded straight into a (H,W,3) u8 view"""
+    from PIL import Image
+    with Image.open(path) as im:
+        a = np.asarray(im.convert("RGB"), dtype=np.uint8)
+    if a.shape != tuple(out_hw3.shape):
+        raise ValueError(f"{path}: decoded {a.shape}, header promised {tuple(out_hw3.shape)}")
+    out_hw3[...] = a
+
+
+def plan_batches(files, sizes, batch_size):
+    """-> list of (H, W, [indices into files]): one entry per batch; files of one geometry keep their order"""
+    groups = {}
+    for i, hw in enumerate(sizes):
+        groups.setdefault(hw, []).append(i)
+    plan = []
+    for (h, w), idxs in groups.items():
+        for s in range(0, len(idxs), batch_size):
+            plan.append((h, w, idxs[s:s + batch_size]))
+    return plan
+
+
+class Batch:
+    __slots__ = ("H", "W", "indices", "paths", "u8", "_slot", "_owner")
+
+    def release(self):
+        """hand the pinned buffer back (call once the H2D copy of this batch has completed)"""
+        if self._owner is not None:
+            self._owner._free.put(self._slot)
+            self._owner = None
+
+
+class ShardLoader:
+    """Iterate a shard as decoded, pinned u8 batches with a bounded read-ahead.
+
+        for b in ShardLoader(files, 32):    # b.u8: pinned (B,H,W,3) uint8 tensor
+            ...; b.release()
+    A decode error is re-raised in the consumer at the position of the failing batch."""
+
+    def __init__(self, files, batch_size=32, workers=None, depth=3, pin=True):
+        self.files = list(files)
+        self.batch_size, self.depth = int(batch_size), max(1, int(depth))
+        self.workers = workers or min(16, max(2, (os.cpu_count() or 4)))
+        self.pin = pin and torch.cuda.is_available()
+        self._pool = ThreadPoolExecutor(max_workers=self.workers)
+        self.sizes = list(self._pool.map(image_size, self.files))                 # header pass, no pixel decode
+        self.plan = plan_batches(self.files, self.sizes, self.batch_size)
+        self._free = queue.Queue()
+        for s in range(self.depth + 2):      # the consumer holds up to two batches (GPU in flight + being written out)
+            self._free.put(s)
+        self._slots = {}
+        self._q = queue.Queue(maxsize=self.depth)
+        self._stop = False
+        self._thread = threading.Thread(target=self._produce, name="sgic-ingest", daemon=True)
+        self._thread.start()
+
+    def __len__(self):
+        return len(self.plan)
+
+    def _buffer(self, slot, nbytes):
+        """slot-owned flat pinned buffer, grown on demand; a batch views its first B*H*W*3 bytes"""
+        t = self._slots.get(slot)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(nbytes, dtype=torch.uint8)
+            if self.pin:
+                t = t.pin_memory()
+            self._slots[slot] = t
+        return t
+
+    def _produce(self):
+        try:
+            for (h, w, idxs) in self.plan:
+                while True:                      # wait for a free pinned slot (bounded memory), but notice close()
+                    if self._stop:
+                        return
+                    try:
+                        slot = self._free.get(timeout=0.1)
+                        break
+                    except queue.Empty:
+                        continue
+                n = len(idxs)
+                flat = self._buffer(slot, n * h * w * 3)
+                u8 = flat[:n * h * w * 3].view(n, h, w, 3)
+                arr = u8.numpy()
+                list(self._pool.map(lambda j: decode_rgb_u8(self.files[idxs[j]], arr[j]), range(n)))
+                b = Batch()
+                b.H, b.W, b.indices, b.paths, b.u8, b._slot, b._owner = h, w, idxs, [self.files[i] for i in idxs], u8, slot, self
+                self._q.put(b)
+            self._q.put(None)
+        except BaseException as e:               # surfaces in the consumer
+            self._q.put(e)
+
+    def __iter__(self):
+        while True:
+            item = self._q.get()
+            if item is None:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+
+    def close(self):
+        self._stop = True
+        try:
+            while True:
+                self._q.get_nowait()
+        except queue.Empty:
+            pass
+        self._thread.join(timeout=5)
+        self._pool.shutdown(wait=False)
+
+
+class DeviceIngest:
+    """u8 batch -> padded fp32 NCHW on the device: async H2D on a copy stream + the fused convert/pad kernel"""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+
+    def __call__(self, batch, pad):
+        """pad = (pl, pr, pt, pb) of compress.py:258-261 -> x (B,3,Hp,Wp) fp32 in [-1,1] on the launch stream"""
+        from . import ops
+        with torch.cuda.stream(self.copy_stream):
+            d = torch.empty(batch.u8.shape, dtype=torch.uint8, device=self.device)
+            d.copy_(batch.u8, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+        cur = torch.cuda.current_stream()
+        cur.wait_event(done)
+        d.record_stream(cur)
+        x = ops.u8hwc_to_f32chw_pad(d, *pad)
+        return x, done

@@ -19,6 +19,17 @@ def _get(d, *path, default=None):
     return default if d is None else d
 
 
+def load_checkpoint(path, ignore_keys=()):
+    """init_from_ckpt (codec_sq_fixbpp.py:494-507) without the unpickler: `weights_only=True` never executes code from
+    the file; a {"state_dict": ...} wrapper is unwrapped; keys starting with an ignore_keys entry are dropped; keys the
+    inference path does not know (vqgan.encoder.*, img_loss.*) stay in the dict and are simply never read
+    (the reference loads with strict=False)."""
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    if isinstance(sd, dict) and "state_dict" in sd:
+        sd = sd["state_dict"]
+    return {k: v for k, v in sd.items() if not any(k.startswith(ik) for ik in ignore_keys)}
+
+
 class Codec(_Codec):
     def __init__(self, embed_dim, feat_dim, in_pos_enc, in_pos_dec, n_attn, config, vqganconfig, imglossconfig=None,
                  featlossconfig=None, training_strategy=None, monitor="", ckpt_path=None, ignore_keys=(),
@@ -42,9 +53,7 @@ class Codec(_Codec):
         if _get(vq, "vit_dec_model_size", default=cfg.model_size) != cfg.model_size or not _get(vq, "use_l2_norm", default=True):
             raise NotImplementedError("encoder/decoder ViT sizes must match and use_l2_norm must be True")
         if ckpt_path is not None:
-            sd = torch.load(ckpt_path, map_location="cpu", weights_only=True)   # never unpickles code
-            sd = sd.get("state_dict", sd)
-            sd = {k: v for k, v in sd.items() if not any(k.startswith(ik) for ik in ignore_keys)}  # codec_sq_fixbpp.py:498-503
+            sd = load_checkpoint(ckpt_path, ignore_keys)
         else:
             print("[Warning] ckpt_path is None: using deterministic synthetic weights")
             sd = W.synth_weights(W.full_spec(cfg), seed=1234)

@@ -624,6 +624,15 @@ def pad_replicate(x, pl, pr, pt, pb):
     return out
 
 
+def u8hwc_to_f32chw_pad(x_u8, pl=0, pr=0, pt=0, pb=0):
+    """(B,H,W,3) u8 device tensor -> (B,3,H+pt+pb,W+pl+pr) fp32 in [-1,1]: ToTensor, *2-1, replicate pad (compress.py:161-164,258-261)"""
+    assert x_u8.dim() == 4 and x_u8.shape[3] == 3 and x_u8.dtype == torch.uint8 and x_u8.is_contiguous() and x_u8.is_cuda
+    B, H, W, _ = x_u8.shape
+    out = torch.empty(B, 3, H + pt + pb, W + pl + pr, device=x_u8.device, dtype=torch.float32)
+    call("sgic_u8hwc_to_f32chw_pad", _p(x_u8), _p(out), B, H, W, int(pl), int(pr), int(pt), int(pb))
+    return out
+
+
 def topk_rows(scores, k):
     """scores (nq, n) fp32 on device (consumed) -> (top scores (nq,k), indices (nq,k) int32)"""
     nq, n = scores.shape

@@ -14,43 +14,64 @@ import numpy as np
 import torch
 
 
-def l2n(x, axis=-1, eps=1e-9):
-    n = np.linalg.norm(x, axis=axis, keepdims=True)
-    return x / np.maximum(n, eps)
+class NotSearchable(ValueError):
+    """a .c2df whose embedded CLIP code is absent or inconsistent with its own metadata"""
 
 
-def dequantize_clip_u8(q):
-    z = (q.astype(np.float32) / 255.0) * 2.0 - 1.0
-    return l2n(z.astype(np.float32))
+def unit_rows(x, floor=1e-9):
+    """rows scaled to unit length; a zero row stays zero instead of dividing by zero"""
+    x = np.asarray(x, dtype=np.float32)
+    length = np.sqrt(np.sum(x * x, axis=-1, keepdims=True))
+    return x / np.maximum(length, floor)
 
 
-def decode_clip_from_c2df(path):
+def codes_to_unit(codes_u8):
+    """inverse of the compress side's u8 quantiser (compress.py:77, `round((z*0.5+0.5)*255)`): code c -> c/255*2-1,
+    then back onto the unit sphere (the quantiser moved the vector off it by up to half a step per coordinate)"""
+    return unit_rows(np.asarray(codes_u8, dtype=np.float32) * np.float32(2.0 / 255.0) - np.float32(1.0))
+
+
+def embedded_clip_vector(path):
+    """query-c2df (search.py:20-41): the CLIP vector a .c2df carries -- entry `clip_stream` is a zstd frame of `dim` u8
+    codes, `clip_meta["dim"]` says how many.  -> (unit vector (dim,) fp32, container header)"""
     from .filemaker import unpack_c2df
     from .zstd import decompress
-    enc, header = unpack_c2df(path)
-    if "clip_stream" not in enc or "clip_meta" not in enc:
-        raise ValueError(f"{path} No 'clip_stream' or 'clip_meta' was found, this file can't be used to search!")
-    dim = int((enc["clip_meta"] or {}).get("dim", 0))
-    if dim <= 0:
-        raise ValueError(f"{path} Invalid clip_meta.dim")
-    q = np.frombuffer(decompress(enc["clip_stream"]), dtype=np.uint8)
-    if q.size != dim:
-        raise ValueError(f"{path} Dimension didn't match: q={q.size}, dim={dim}")
-    return dequantize_clip_u8(q).astype("float32"), header
+    entries, header = unpack_c2df(path)
+    stream, meta = entries.get("clip_stream"), entries.get("clip_meta")
+    if stream is None or meta is None:
+        raise NotSearchable(f"{path}: container has no embedded CLIP code (entries clip_stream / clip_meta), it cannot be used as a query")
+    want = int((meta or {}).get("dim", 0) or 0)
+    if want <= 0:
+        raise NotSearchable(f"{path}: clip_meta carries no positive 'dim'")
+    codes = np.frombuffer(decompress(stream), dtype=np.uint8)
+    if codes.size != want:
+        raise NotSearchable(f"{path}: clip_stream decodes to {codes.size} codes but clip_meta.dim says {want}")
+    return codes_to_unit(codes), header
+
+
+# names of the reference script (search.py:16-41), kept so that code written against it keeps importing
+l2n = unit_rows
+dequantize_clip_u8 = codes_to_unit
+decode_clip_from_c2df = embedded_clip_vector
+
+# the two on-disk layouts the reference's tools produce: build.py writes (faiss.index, paths.json), compress.py writes
+# (index.faiss, ids.txt) -- search.py:65-88 accepts either
+_INDEX_LAYOUTS = (("faiss.index", "paths.json", lambda t: list(json.loads(t))),
+                  ("index.faiss", "ids.txt", lambda t: [ln.strip() for ln in t.splitlines() if ln.strip()]))
 
 
 def load_index(index_dir):
+    """-> (database (n, d) fp32, doc ids [n]) from whichever layout is present in index_dir"""
     from .faiss_io import read_index_flat_ip
-    index_dir = Path(index_dir)
-    if (index_dir / "faiss.index").exists() and (index_dir / "paths.json").exists():
-        vecs = read_index_flat_ip(str(index_dir / "faiss.index"))
-        paths = json.loads((index_dir / "paths.json").read_text(encoding="utf-8"))
-    elif (index_dir / "index.faiss").exists() and (index_dir / "ids.txt").exists():
-        vecs = read_index_flat_ip(str(index_dir / "index.faiss"))
-        paths = [ln.strip() for ln in (index_dir / "ids.txt").read_text(encoding="utf-8").splitlines() if ln.strip()]
-    else:
-        raise FileNotFoundError(f"Can't find FAISS index in {index_dir}")
-    return vecs, paths
+    root = Path(index_dir)
+    for index_name, ids_name, parse in _INDEX_LAYOUTS:
+        fi, fp = root / index_name, root / ids_name
+        if fi.exists() and fp.exists():
+            vecs, ids = read_index_flat_ip(str(fi)), parse(fp.read_text(encoding="utf-8"))
+            if len(ids) != vecs.shape[0]:
+                raise ValueError(f"{root}: {index_name} holds {vecs.shape[0]} vectors but {ids_name} lists {len(ids)} ids")
+            return vecs, ids
+    raise FileNotFoundError(f"no FAISS index in {root}: expected " + " or ".join(f"{a} + {b}" for a, b, _ in _INDEX_LAYOUTS))
 
 
 def tokenize(text, ctx=77, token_ids=None):

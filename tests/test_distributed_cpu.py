@@ -41,6 +41,62 @@ def test_shard_and_gather_world2():
         assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == n_total
 
 
+_STEMS = ["img_10", "img_2", "a", "a-1", "a.b", "B", "zeta", "a_2", "0007", "Alpha", "b"]
+
+
+def _vec_of(stem, d=16):
+    import zlib
+    r = np.random.default_rng(zlib.crc32(stem.encode()))
+    v = r.standard_normal(d).astype(np.float32)
+    return v / np.linalg.norm(v)
+
+
+def _index_worker(rank, world, port, root, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", init_method="env://", rank=rank, world_size=world)
+    import sgic_amd  # noqa
+    from sgic_amd.compress import assemble_index, stem_of
+    from sgic_amd.dist import gather_vectors, shard_range
+    # what compress.py does per rank: sorted file list -> contiguous shard -> one vector per file -> gather -> rank 0 index
+    files = sorted(os.path.join(root, "in", s + ext) for s, ext in zip(_STEMS, [".jpg", ".png"] * 6))
+    lo, hi = shard_range(len(files), rank, world)
+    local = torch.from_numpy(np.stack([_vec_of(stem_of(f)) for f in files[lo:hi]]))
+    for f in files[lo:hi]:                                   # every rank wrote the .c2df files of its shard
+        if stem_of(f) != "zeta":                             # ... except one that "failed": it must stay out of the index
+            open(os.path.join(root, "bit", stem_of(f) + ".c2df"), "wb").close()
+    dist.barrier()
+    allv = gather_vectors(local, len(files), rank, world).numpy()
+    ids = assemble_index(files, allv, os.path.join(root, "bit"), os.path.join(root, "idx"), 16) if rank == 0 else None
+    q.put((rank, ids))
+    dist.destroy_process_group()
+
+
+def test_rank0_index_assembly_order_world2(tmp_path):
+    """compress.py:295-306: ids.txt / index rows follow sorted(glob(clip_vecs/*.npy)) = stems ordered by "<stem>.npy",
+    only stems whose .c2df exists, doc id = join(bit_dir, stem + ".c2df"); vectors come through the all-gather"""
+    root = str(tmp_path)
+    for d in ("in", "bit", "idx"):
+        os.makedirs(os.path.join(root, d))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_index_worker, args=(r, 2, port, root, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = dict(q.get(timeout=120) for _ in ps)
+    [p.join(timeout=60) for p in ps]
+    import sgic_amd  # noqa
+    from sgic_amd.faiss_io import read_index_flat_ip
+    want = [s for s in sorted(_STEMS, key=lambda s: s + ".npy") if s != "zeta"]
+    # "<stem>.npy" order, not bare-stem order: "a.b.npy" < "a.npy" (b < n) although "a" < "a.b"
+    assert want.index("a-1") < want.index("a.b") < want.index("a") < want.index("a_2") and sorted(want) != want
+    ids = [ln for ln in open(os.path.join(root, "idx", "ids.txt")).read().splitlines()]
+    assert ids == [os.path.join(root, "bit", s + ".c2df") for s in want] == res[0]
+    v = read_index_flat_ip(os.path.join(root, "idx", "index.faiss"))
+    assert v.shape == (len(want), 16)
+    for row, s in zip(v, want):
+        assert np.allclose(row, _vec_of(s), atol=1e-6), s
+
+
 def test_shard_range_partitions():
     import sgic_amd  # noqa
     from sgic_amd.dist import shard_range

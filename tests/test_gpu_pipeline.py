@@ -83,3 +83,54 @@ def test_search_topk_parity_10k_corpus(tmp_path):
         if not np.array_equal(i[r], ref[r]):
             assert set(i[r]) == set(ref[r]) or np.abs(np.sort(full[r, i[r]])[::-1] - np.sort(full[r, ref[r]])[::-1]).max() < 1e-6, r
         assert np.allclose(s[r], full[r, i[r]], atol=1e-5)
+
+
+def test_u8_ingest_kernel_bit_exact_vs_torch():
+    """sgic_u8hwc_to_f32chw_pad == transforms.ToTensor()(img) * 2.0 - 1.0 followed by F.pad(replicate) (compress.py:161-164,
+    258-261), bit for bit, for every byte value and ragged geometries"""
+    import sgic_amd  # noqa
+    from sgic_amd import ops
+    rng = np.random.default_rng(3)
+    for (B, H, W, pad) in [(3, 200, 300, (0, 212, 0, 56)), (2, 256, 256, (0, 0, 0, 0)), (1, 1, 1, (0, 255, 0, 255)), (2, 17, 33, (3, 5, 2, 7))]:
+        a = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+        a.reshape(-1)[:256] = np.arange(256, dtype=np.uint8)[:a.size]
+        ref = torch.from_numpy(a).permute(0, 3, 1, 2).float().div(255.0) * 2.0 - 1.0
+        ref = torch.nn.functional.pad(ref, pad, mode="replicate")
+        got = ops.u8hwc_to_f32chw_pad(torch.from_numpy(a).cuda(), *pad).cpu()
+        assert got.shape == ref.shape and torch.equal(got, ref), (B, H, W, pad)
+
+
+def test_streaming_compress_equals_per_image_encode_only(tmp_path):
+    """the streamed, batched CLI writes, for every file, the bytes `encode_only` + `ClipCodec` give for that image alone
+    (reference loop, compress.py:248-291): batching / ingest / pipelining change nothing in the .c2df"""
+    from PIL import Image
+    import sgic_amd  # noqa
+    from sgic_amd import compress, ops
+    from sgic_amd import weights as W
+    from sgic_amd.codec import ClipCodec, Codec
+    from sgic_amd.config import CLIP_TINY, SMALL
+    from sgic_amd.data import synth_images
+    from sgic_amd.entropy.compression_model import get_padding_size
+    from sgic_amd.filemaker import unpack_c2df
+    src = tmp_path / "imgs"
+    src.mkdir()
+    sizes = [(256, 256), (200, 300), (256, 256), (256, 256), (200, 300), (300, 520), (256, 256)]
+    for i, (h, w) in enumerate(sizes):
+        x = synth_images(1, 768, 768, 500 + i)[0, :, :h, :w]
+        Image.fromarray(((x * 0.5 + 0.5) * 255).round().byte().permute(1, 2, 0).numpy()).save(src / f"f{i}.png")
+    out = tmp_path / "out"
+    assert compress.main(["--dataset_dir", str(src), "--save_dir", str(out), "--small", "--batch_size", "3", "--prefetch", "2"]) == 0
+    sd = W.synth_weights(W.encoder_spec(SMALL) + W.codec_misc_spec(SMALL) + W.bottleneck_spec(SMALL), seed=1234)
+    model = Codec(sd, SMALL, "cuda:0")
+    model.hybrid_codec.quantize_feat.force_zero_thres = 0.12
+    model.hybrid_codec.quantize_feat.update(force=True)
+    clipc = ClipCodec(W.synth_weights(W.clip_spec(CLIP_TINY), seed=4321), CLIP_TINY, "cuda:0")
+    for i, (h, w) in enumerate(sizes):
+        img = compress.load_image(str(src / f"f{i}.png")).cuda()[None]
+        pad = get_padding_size(h, w, p=256)
+        ref = model.encode_only(torch.nn.functional.pad(img, pad, mode="replicate"))
+        enc, hdr = unpack_c2df(out / "bitstreams" / f"f{i}.c2df")
+        assert enc["h_bit_stream"] == ref["h_bit_stream"] and enc["z_bit_stream"] == ref["z_bit_stream"], i
+        assert tuple(enc["img_shape"]) == tuple(ref["img_shape"]) and hdr["padding"] == list(pad) and hdr["image_hw"] == [h, w]
+        v = clipc.image_to_unit_vec(img[0])
+        assert np.allclose(np.load(out / "clip_vecs" / f"f{i}.npy"), v, atol=1e-6), i
