@@ -213,10 +213,34 @@ class BottleneckHIP:
         return self.synthesis(y_hat, B, H, W)
 
     @staticmethod
-    def streams_to_host(out, meta):
-        """one D2H copy of the slots + (off, len, err); returns list[bytes]"""
-        h_meta = meta.cpu().numpy()
-        if int(np.abs(h_meta[2]).sum()) != 0:
-            raise RuntimeError(f"rANS encode error codes {h_meta[2].tolist()} (slot too small or bad index)")
-        h_out = out.cpu().numpy()
-        return [h_out[b, h_meta[0, b]:h_meta[0, b] + h_meta[1, b]].tobytes() for b in range(out.shape[0])]
+    def streams_to_host(out, meta, retry=None):
+        """one D2H copy of the slots + (off, len, err); returns list[bytes].  retry = (table, sym, idx, n): images whose
+        slot was too small are re-encoded on their own (see slice_streams)."""
+        return slice_streams(out.cpu().numpy(), meta.cpu().numpy(), retry)
+
+
+SGIC_ENOSPC = -3
+
+
+def slice_streams(h_out, h_meta, retry=None):
+    """host copies of the (B, cap) slots and the (3, B) off/len/err rows -> list[bytes].
+    The batched encoder gives every image a 2n+64-byte slot, which a bypass-heavy image can overflow (SGIC_ENOSPC).  Such
+    an image is re-encoded ALONE with the hard bound 16n+64 -- its symbols / indexes are still on the device -- instead of
+    failing the whole batch (the per-image facade RansEncoder.flush does the same; the reference coder grows a vector).
+    Any other error code (an index outside the table: SGIC_EINVAL) is a real fault and raises."""
+    B = h_out.shape[0]
+    res = []
+    for b in range(B):
+        err = int(h_meta[2, b])
+        if err == 0:
+            res.append(h_out[b, h_meta[0, b]:h_meta[0, b] + h_meta[1, b]].tobytes())
+        elif err == SGIC_ENOSPC and retry is not None:
+            table, sym, idx, n = retry
+            out1, meta1 = ops.rans_encode_batch(table, sym[b:b + 1].contiguous(), idx[b:b + 1].contiguous(), 1, n, cap=16 * n + 64)
+            m1 = meta1.cpu().numpy()
+            if int(m1[2, 0]) != 0:
+                raise RuntimeError(f"rANS encode failed for image {b} even with the 16n+64 bound: code {int(m1[2, 0])}")
+            res.append(out1.cpu().numpy()[0, m1[0, 0]:m1[0, 0] + m1[1, 0]].tobytes())
+        else:
+            raise RuntimeError(f"rANS encode error code {err} for image {b} of the batch (codes {h_meta[2].tolist()})")
+    return res

@@ -86,14 +86,15 @@ class Codec:
                 t.record_stream(torch.cuda.current_stream())
         else:
             out, meta = ops.rans_encode_batch(bn.tables.handles[bn.group], sym, idx, B, n)
-        return dict(z=z, h=h, vq=vq, zs=zs, hs=out, hmeta=meta, sym=sym, idx=idx, stack=(nH, nW), feat_hw=(hh, ww), ntok=ntok)
+        return dict(z=z, h=h, vq=vq, zs=zs, hs=out, hmeta=meta, sym=sym, idx=idx, n=n, stack=(nH, nW), feat_hw=(hh, ww), ntok=ntok)
 
     def encode_batch(self, x):
         """-> list of B enc_result dicts (the reference's encode_only contract, one per image)"""
         cfg = self.cfg
         B, _, H, W = x.shape
         r = self.encode_device(x)
-        h_streams = BottleneckHIP.streams_to_host(r["hs"], r["hmeta"])
+        bn = self.bottleneck
+        h_streams = BottleneckHIP.streams_to_host(r["hs"], r["hmeta"], retry=(bn.tables.handles[bn.group], r["sym"], r["idx"], r["n"]))
         zs = r["zs"].cpu().numpy()
         nH, nW = r["stack"]
         hh, ww = r["feat_hw"]

@@ -62,14 +62,14 @@ class CompressPipeline:
         p, B = h["p"], h["B"]
         h["ev"].synchronize()
         p["busy"] = False
-        meta = p["meta"].numpy()
-        if int(np.abs(meta[2]).sum()) != 0:
-            raise RuntimeError(f"rANS encode error codes {meta[2].tolist()}")
-        hs, zs, qh = p["hs"].numpy(), p["zs"].numpy(), p["q"].numpy()
+        from .bottleneck import slice_streams
+        bn, r = self.codec.bottleneck, h["r"]
+        # an image whose rANS slot overflowed is re-encoded on its own (its symbols are still on the device), not the batch
+        h_streams = slice_streams(p["hs"].numpy(), p["meta"].numpy(), retry=(bn.tables.handles[bn.group], r["sym"], r["idx"], r["n"]))
+        zs, qh = p["zs"].numpy(), p["q"].numpy()
         out = []
         for b in range(B):
-            d = dict(z_bit_stream=zs[b].tobytes(), h_bit_stream=hs[b, meta[0, b]:meta[0, b] + meta[1, b]].tobytes(),
-                     clip_stream=self.clipc.compress_codes(qh[b]))
+            d = dict(z_bit_stream=zs[b].tobytes(), h_bit_stream=h_streams[b], clip_stream=self.clipc.compress_codes(qh[b]))
             if self.want_unit:
                 d["clip_unit"] = p["unit"][b].numpy().copy()
             out.append(d)

@@ -7,6 +7,7 @@ package is importable and otherwise takes ready-made ids via --token_ids.  The s
 database^T) + a top-k kernel on the GPU."""
 import argparse
 import json
+import os
 import sys
 from pathlib import Path
 
@@ -37,6 +38,7 @@ def embedded_clip_vector(path):
     from .filemaker import unpack_c2df
     from .zstd import decompress
     entries, header = unpack_c2df(path)
+    path = path if isinstance(path, (str, os.PathLike)) else "<c2df bytes>"    # unpack_c2df also takes the file's bytes
     stream, meta = entries.get("clip_stream"), entries.get("clip_meta")
     if stream is None or meta is None:
         raise NotSearchable(f"{path}: container has no embedded CLIP code (entries clip_stream / clip_meta), it cannot be used as a query")

@@ -295,3 +295,35 @@ def test_torchac_shim_vs_reference_sample_and_oracle(golden_dir):
         torchac.encode_float_cdf((cdf ** 2).unsqueeze(0), torch.zeros(1, dtype=torch.int16))
     with pytest.raises(ValueError):
         torchac.decode_float_cdf(shaped, z[:-1])
+
+
+def test_overflowing_image_is_reencoded_alone_not_the_batch(tab):
+    """batched path (pipeline.finish / encode_batch -> bottleneck.slice_streams): one bypass-heavy image overflows its
+    2n+64 slot (SGIC_ENOSPC); it is re-encoded on its own with the 16n+64 bound and the other images of the batch keep
+    their streams -- all equal to the oracle's.  A bad index (EINVAL) still raises."""
+    import sgic_amd  # noqa
+    from sgic_amd import ops
+    from sgic_amd.bottleneck import SGIC_ENOSPC, slice_streams
+    from sgic_amd.entropy.MLCodec_rans import _Tables
+    T = _Tables()
+    gid = T.add(*tab)
+    otab = orc.Table(*tab)
+    rng = np.random.default_rng(5)
+    B, n = 3, 512
+    sym = rng.integers(-3, 4, (B, n)).astype(np.int16)
+    idx = rng.integers(0, 256, (B, n)).astype(np.int16)
+    sym[1] = rng.choice(np.array([-30000, 30000], dtype=np.int16), n)        # every symbol of image 1 takes the bypass path
+    ds, di = torch.from_numpy(sym).cuda(), torch.from_numpy(idx).cuda()
+    out, meta = ops.rans_encode_batch(T.handles[gid], ds, di, B, n)
+    m = meta.cpu().numpy()
+    assert m[2].tolist() == [0, SGIC_ENOSPC, 0]
+    with pytest.raises(RuntimeError):
+        slice_streams(out.cpu().numpy(), m)                                    # without the device data there is nothing to retry from
+    got = slice_streams(out.cpu().numpy(), m, retry=(T.handles[gid], ds, di, n))
+    for b in range(B):
+        assert got[b] == orc.rans_encode(sym[b], idx[b], otab), b
+    assert len(got[1]) > 2 * n + 64
+    idx[2, 7] = 300                                                            # outside the 256-row table
+    out, meta = ops.rans_encode_batch(T.handles[gid], ds, torch.from_numpy(idx).cuda(), B, n)
+    with pytest.raises(RuntimeError):
+        slice_streams(out.cpu().numpy(), meta.cpu().numpy(), retry=(T.handles[gid], ds, torch.from_numpy(idx).cuda(), n))
