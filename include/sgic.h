@@ -92,6 +92,11 @@ int sgic_scale_to_index(const float *d_scales, long n, float thr, int16_t *d_idx
  * y_hat[active] = sym + mean after the symbols were decoded. */
 int sgic_index_step(const float *d_scales, int ld_sm, int B, int H, int W, int C, int k, float thr,
                     int16_t *d_idx, sgic_stream_t stream);
+/* Decision margins of sgic_index_step for step k (robust decoding of streams written by another fp32 implementation):
+ * d_margin (B,4,C/4,H,W) float = distance of each coded sigma, in index steps, to the nearest boundary of build_indexes
+ * (a bin edge or the skip threshold; entropy_models.py:355-362), d_alt = the index on the other side of that boundary. */
+int sgic_index_margins(const float *d_scales, int ld_sm, int B, int H, int W, int C, int k, float thr, float *d_margin,
+                       int16_t *d_alt, sgic_stream_t stream);
 int sgic_dequant_step(const int16_t *d_sym, const float *d_means, int ld_sm, float *d_yhat, int ld_yhat, int B,
                       int H, int W, int C, int k, sgic_stream_t stream);
 

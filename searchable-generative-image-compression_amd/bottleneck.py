@@ -167,10 +167,12 @@ class BottleneckHIP:
         h = ops.colop(h, self.dec_q, 0)
         return dcb4_forward(dcb4_forward(h, self.dec1[0], B, H, W), self.dec1[1], B, H, W)
 
-    def decode_latent(self, streams, off, ln, cap, B, H, W):
+    def decode_latent(self, streams, off, ln, cap, B, H, W, overrides=None, margins=False):
         """decompress_four_part_prior for a batch (entropy/compression_model.py:377-418): the 4 x {prior NN ->
         indexes -> rANS decode -> dequantise} dependency chain runs entirely on the GPU, all B streams in
-        parallel (one lane per stream, cursor kept in HBM between steps).  streams (B,cap) u8 on device."""
+        parallel (one lane per stream, cursor kept in HBM between steps).  streams (B,cap) u8 on device.
+        overrides: [(b, k, flat position in the (Q/4,H,W) step slice, index)] forced after the index builder of step k;
+        margins=True also returns the decision margins of every index (robust decoding, see decompress)."""
         Q, hw = self.Q, H * W
         paramsB, commonB = self._prior(B, H, W)
         ctx = torch.zeros(B * hw, 2 * Q, device=self.device)
@@ -178,6 +180,10 @@ class BottleneckHIP:
         n = (Q // 4) * hw
         sym = torch.zeros(B, 4, Q // 4, H, W, dtype=torch.int16, device=self.device)
         idx = torch.zeros_like(sym)
+        marg = alt = None
+        if margins:
+            marg = torch.empty(B, 4, Q // 4, H, W, dtype=torch.float32, device=self.device)
+            alt = torch.empty_like(sym)
         thr = self.force_zero_thres
         tab = self.tables.handles[self.group]
         state = ops.rans_decode_init(streams, cap, off, ln, B)
@@ -191,14 +197,84 @@ class BottleneckHIP:
                     t = dcb4_forward(t, w, B, H, W)
                 sc, mu, ld = t[:, 0:Q], t[:, Q:], 2 * Q
             ops.index_step(sc, ld, B, H, W, Q, k, thr, idx)
+            if margins:
+                ops.index_margins(sc, ld, B, H, W, Q, k, thr, marg, alt)
+            for (ob, ok, opos, oidx) in (overrides or ()):
+                if ok == k:
+                    idx_f[(ob * 4 + k) * n + opos] = int(oidx)          # a 2-byte device store, no arithmetic
             ops.rans_decode_step(tab, streams, cap, off, ln, B, state, idx_f[k * n:], n, 4 * n, sym_f[k * n:], 4 * n)
             ops.dequant_step(sym, mu, ld, ctx, 2 * Q, B, H, W, Q, k)
         y_hat = ops.colop(ctx[:, 0:Q], paramsB[:, 0:Q], 2)           # y_hat_so_far * clamp_min(q_step, 0.5)
+        if margins:
+            return y_hat, state, sym, idx, marg, alt
         return y_hat, state, sym, idx
+
+    RANS_L = 1 << 23
+
+    @classmethod
+    def stream_status(cls, state_host, lengths):
+        """per image: 0 = decoded cleanly (no error flag, every byte consumed, final coder state == the encoder's
+        initial state RANS_L), else why not.  rANS is self-checking at the end of a stream: a decoder that took one wrong
+        cdf row anywhere ends in a different state / at a different byte with overwhelming probability."""
+        st = []
+        for b, n in enumerate(lengths):
+            x, pos, err = int(state_host[b, 0]) & 0xFFFFFFFF, int(state_host[b, 1]), int(state_host[b, 2])
+            st.append(1 if err else (2 if pos != n else (3 if x != cls.RANS_L else 0)))
+        return st
+
+    def _retry_edge_flips(self, stream, H, W, max_margin=5e-4, first=24, second=3):
+        """Robust decode of ONE stream whose plain decode failed the end-of-stream check (B = 1).
+        A stream written by another fp32 implementation of the same network (the reference on a CPU or another GPU)
+        was coded with that implementation's sigma; ours differs by summation-order noise of a few ulps, and a sigma
+        that sits within that noise of a decision boundary of build_indexes gets a different index here -- one such
+        index desynchronises the rest of the stream.  Cure: re-decode with the nearest-to-a-boundary indexes flipped to
+        the other side, earliest step first, one at a time (then pairs), until the end-of-stream check passes.  The
+        candidates are few (margin < 5e-4 index steps: ~1e-5 relative in sigma) and every attempt is verified."""
+        buf = torch.from_numpy(np.frombuffer(stream, dtype=np.uint8).copy()).to(self.device)[None]
+        ln = torch.tensor([len(stream)], dtype=torch.int32, device=self.device)
+        n = (self.Q // 4) * H * W
+
+        def attempt(ov):
+            y, state, _, idx, marg, alt = self.decode_latent(buf, None, ln, len(stream), 1, H, W, overrides=ov, margins=True)
+            ok = self.stream_status(state.cpu().numpy(), [len(stream)])[0] == 0
+            return ok, y, marg.view(4, n).cpu().numpy(), alt.view(4, n).cpu().numpy()
+
+        def candidates(marg, alt, from_step, taken, limit):
+            """nearest-to-a-boundary first, over all steps >= from_step (a genuine flip sits at ~1e-5 index steps; in
+            the steps after the first wrong index sigma is garbage, so spurious small margins there rank behind it)"""
+            ks, ps = np.nonzero(marg[from_step:] < max_margin)
+            order = np.argsort(marg[from_step:][ks, ps], kind="stable")
+            out = []
+            for o in order:
+                k, p = int(ks[o]) + from_step, int(ps[o])
+                if (k, p) not in taken:
+                    out.append((0, k, p, int(alt[k, p])))
+                if len(out) >= limit:
+                    break
+            return out
+
+        ok, y, marg, alt = attempt(None)
+        if ok:
+            return y, 0
+        tries = 0
+        for c1 in candidates(marg, alt, 0, set(), first):
+            ok, y, m1, a1 = attempt([c1])
+            tries += 1
+            if ok:
+                return y, tries
+            for c2 in candidates(m1, a1, c1[1], {(c1[1], c1[2])}, second):
+                ok, y, _, _ = attempt([c1, c2])
+                tries += 1
+                if ok:
+                    return y, tries
+        raise RuntimeError("h_bit_stream does not decode: the end-of-stream check failed and no near-boundary index flip "
+                           f"repairs it ({tries} verified attempts) -- corrupt stream, or written with different weights")
 
     def decompress(self, h_streams, B, H, W):
         """Compressive_bottleneck_varbpp_type2.decompress for a batch (models/sq_bottleneck.py:185-199):
-        list of B h_bit_stream byte strings -> h_hat [(B*H*W), Fd] plain NHWC on device"""
+        list of B h_bit_stream byte strings -> h_hat [(B*H*W), Fd] plain NHWC on device.
+        Unlike the reference (which over-reads silently, rans.cpp:53-68) every stream is verified at its end; a stream
+        that fails is re-decoded on its own with near-boundary indexes flipped (_retry_edge_flips)."""
         if self.tables is None:
             raise RuntimeError("call update(force=True) first")
         cap = max(len(s) for s in h_streams)
@@ -208,8 +284,13 @@ class BottleneckHIP:
         streams = torch.from_numpy(buf).to(self.device)
         ln = torch.tensor([len(s) for s in h_streams], dtype=torch.int32, device=self.device)
         y_hat, state, _, _ = self.decode_latent(streams, None, ln, cap, B, H, W)
-        if int(state[:, 2].abs().sum().item()) != 0:
-            raise RuntimeError("corrupt h_bit_stream: rANS decoder ran past the end of a stream or hit a bad index")
+        status = self.stream_status(state.cpu().numpy(), [len(s) for s in h_streams])
+        self.last_repairs = 0
+        for b, st in enumerate(status):
+            if st:
+                yb, tries = self._retry_edge_flips(h_streams[b], H, W)
+                y_hat[b * H * W:(b + 1) * H * W].copy_(yb)            # device-to-device row copy
+                self.last_repairs += 1
         return self.synthesis(y_hat, B, H, W)
 
     @staticmethod

@@ -592,6 +592,57 @@ extern "C" int sgic_index_step(const float *d_scales, int ld_sm, int B, int H, i
   return sgic::check_launch("quant_step_kernel<1>");
 }
 
+// Decision margins of the index builder for step k: how far (in units of one index step, i.e. of ln(sigma) / log_step) each
+// coded position is from the nearest decision boundary of build_indexes -- a bin edge of the 256-level scale table or the
+// force-zero / skip threshold -- and the index the OTHER side of that boundary would give.  A decoder that reads a
+// stream made by a different fp32 implementation (the reference on a CPU / another GPU) sees sigma with a few ulps of
+// summation-order noise; a sigma sitting within that noise of a boundary can flip an index and desynchronise rANS.  The
+// host uses these margins to retry such a decode with the near-boundary index flipped (bottleneck.py), which the rANS
+// end-of-stream condition then verifies.  d_margin / d_alt: (B, 4, C/4, H, W), step-k slice written.
+__global__ void index_margin_kernel(const float *__restrict__ scales, int ld_sm, int B, int H, int W, int C, int k, float thr,
+                                    float *__restrict__ margin, int16_t *__restrict__ alt) {
+  const int Q = C >> 2;
+  const long total = (long)B * H * W * Q;
+  const double log_min = -2.2072749131897207, log_step = 0.024965325476664284;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(t % Q);
+    const long pos = t / Q;
+    const int j = (int)(pos % W);
+    const int i = (int)((pos / W) % H);
+    const int b = (int)(pos / ((long)W * H));
+    const int ch = active_quarter(i, j, k) * Q + c;
+    const size_t o = ((((size_t)b * 4 + k) * Q + c) * H + i) * W + j;
+    const float sg = scales[pos * ld_sm + ch];
+    const bool skipped = thr >= 0.f && sg < thr;
+    const double ls = log((double)fmaxf(sg, 1e-5f));
+    const int as_coded = scale_to_index(sg, -1.f);          // the index this sigma gets when it is not skipped
+    double best = 1e30;
+    int other = as_coded;
+    if (thr >= 0.f) {                                        // the skip threshold
+      best = fabs(ls - log((double)thr)) / log_step;
+      other = skipped ? as_coded : -1;
+    }
+    if (!skipped) {                                          // bin edges (none below index 0 / above 255: the clamp)
+      const double ti = (ls - log_min) / log_step, f = ti - floor(ti);
+      if (ti > 0.0 && ti < 255.0) {
+        if (as_coded >= 1 && f < best) best = f, other = as_coded - 1;
+        if (as_coded <= 254 && 1.0 - f < best) best = 1.0 - f, other = as_coded + 1;
+      }
+    }
+    margin[o] = (float)best;
+    alt[o] = (int16_t)other;
+  }
+}
+
+extern "C" int sgic_index_margins(const float *d_scales, int ld_sm, int B, int H, int W, int C, int k, float thr,
+                                  float *d_margin, int16_t *d_alt, sgic_stream_t stream) {
+  SGIC_REQUIRE(d_scales && d_margin && d_alt && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && k >= 0 && k < 4 && ld_sm >= C,
+               "args");
+  const long total = (long)B * H * W * (C / 4);
+  index_margin_kernel<<<cdiv(total, 256), 256, 0, to_stream(stream)>>>(d_scales, ld_sm, B, H, W, C, k, thr, d_margin, d_alt);
+  return sgic::check_launch("index_margin_kernel");
+}
+
 extern "C" int sgic_dequant_step(const int16_t *d_sym, const float *d_means, int ld_sm, float *d_yhat, int ld_yhat,
                                  int B, int H, int W, int C, int k, sgic_stream_t stream) {
   SGIC_REQUIRE(d_sym && d_means && d_yhat && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && k >= 0 && k < 4 &&

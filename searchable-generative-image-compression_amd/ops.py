@@ -459,6 +459,10 @@ def index_step(scales, ld_sm, B, H, W, C, k, thr, idx):
     call("sgic_index_step", _p(scales), ld_sm, B, H, W, C, k, float(-1.0 if thr is None else thr), _p(idx))
 
 
+def index_margins(scales, ld_sm, B, H, W, C, k, thr, margin, alt):
+    call("sgic_index_margins", _p(scales), ld_sm, B, H, W, C, k, float(-1.0 if thr is None else thr), _p(margin), _p(alt))
+
+
 def dequant_step(sym, means, ld_sm, yhat, ld_yhat, B, H, W, C, k):
     call("sgic_dequant_step", _p(sym), _p(means), ld_sm, _p(yhat), ld_yhat, B, H, W, C, k)
 
