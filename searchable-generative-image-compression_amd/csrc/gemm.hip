@@ -41,31 +41,32 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_TANH = 3, ACT_LRELU = 4 };
 
-// erf(x) for the exact-GELU epilogue: clamp to [-4,4] and evaluate a (6,4) rational minimax in x^2 -- the
-// float32 erf approximant used by Eigen / XLA (max abs error 4e-7, i.e. fp32 rounding level), branch-free
-// and ~3x cheaper than the libm erff, which matters because every workgroup finishes at the same time.
-__device__ __forceinline__ float fast_erf(float x) {
-  x = fminf(fmaxf(x, -4.f), 4.f);
-  const float x2 = x * x;
-  float p = -2.72614225801306e-10f;
-  p = fmaf(p, x2, 2.77068142495902e-08f);
-  p = fmaf(p, x2, -2.10102402082508e-06f);
-  p = fmaf(p, x2, -5.69250639462346e-05f);
-  p = fmaf(p, x2, -7.34990630326855e-04f);
-  p = fmaf(p, x2, -2.95459980854025e-03f);
-  p = fmaf(p, x2, -1.60960333262415e-02f);
-  p = p * x;
-  float q = -1.45660718464996e-05f;
-  q = fmaf(q, x2, -2.13374055278905e-04f);
-  q = fmaf(q, x2, -1.68282697438203e-03f);
-  q = fmaf(q, x2, -7.37332916720468e-03f);
-  q = fmaf(q, x2, -1.42647390514189e-02f);
-  return p / q;
+// Exact (erf) GELU for the fc1 epilogues: gelu(x) = x * Phi(x) = 0.5 x (1 + erf(x / sqrt 2)), nn.GELU's default.
+// The epilogue of a 128x128 tile evaluates it 64 times per lane while the matrix pipe waits, so its VALU cost is
+// GEMM time (measured with tools/micro/gemm_stamps.hip: a (6,4) rational erf + IEEE division, ~35 VALU operations per
+// element, made the epilogue 15 % of an fc1 tile).  This form is Abramowitz & Stegun 7.1.26 for erfc,
+//     erfc(a) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-a^2),  t = 1 / (1 + p a),  a >= 0,  |error| <= 1.5e-7,
+// with the hardware reciprocal and exp2 (1 ulp each): ~14 VALU operations, branch-free.  1 + erf(z) is taken as
+// 2 - erfc(|z|) for z >= 0 and as erfc(|z|) itself for z < 0, so the negative tail has no cancellation at all
+// (max |gelu error| 4e-7 over [-12, 12], the level of the fp32 rounding of the result).
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = x * 0.70710678118654752440f;
+  const float a = fabsf(z);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.0f));
+  float p = 1.061405429f;
+  p = fmaf(p, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(a * a * -1.44269504088896340736f);   // exp(-a^2)
+  const float erfc_a = p * t * e;
+  const float one_plus_erf = z >= 0.f ? 2.0f - erfc_a : erfc_a;
+  return 0.5f * x * one_plus_erf;
 }
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
-    case ACT_GELU: return 0.5f * v * (1.0f + fast_erf(v * 0.70710678118654752440f));
+    case ACT_GELU: return gelu_erf(v);
     case ACT_SILU: return v / (1.0f + expf(-v));
     case ACT_TANH: return tanhf(v);
     case ACT_LRELU: return v >= 0.f ? v : 0.01f * v;
@@ -75,7 +76,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 template <int ACT>
 __device__ __forceinline__ float apply_act_c(float v) {
-  if constexpr (ACT == ACT_GELU) return 0.5f * v * (1.0f + fast_erf(v * 0.70710678118654752440f));
+  if constexpr (ACT == ACT_GELU) return gelu_erf(v);
   else if constexpr (ACT == ACT_SILU) return v / (1.0f + expf(-v));
   else if constexpr (ACT == ACT_TANH) return tanhf(v);
   else if constexpr (ACT == ACT_LRELU) return v >= 0.f ? v : 0.01f * v;
@@ -86,6 +87,13 @@ template <int V>
 struct IntC {
   static constexpr int value = V;
 };
+
+// Diagnostic build only (tools/micro/gemm_stamps.hip defines GEMM_STAMPS): per workgroup, s_memrealtime at start / end and
+// the main-loop and epilogue cycles of thread 0, into a buffer nothing else reads.  The product build has no stamps.
+#ifdef GEMM_STAMPS
+__device__ long long gemm_stamps[8 * 4096];   // per block: [0] start(real) [1] end(real) [2] loop cycles [3] epilogue cycles [4] tiles [5] life cycles
+#define GS_NOW() ((long long)__builtin_amdgcn_s_memtime())
+#endif
 
 struct GemmArgs {
   const float *A;
@@ -242,8 +250,17 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, int bid, int step, 
     }
   }
   Frag f0, f1;
+#ifdef GEMM_STAMPS
+  long long gs_t0 = 0, gs_loop = 0, gs_epi = 0;
+  int gs_tiles = 0;
+  if (threadIdx.x == 0 && blockIdx.x < 4096) gemm_stamps[blockIdx.x * 8 + 0] = (long long)__builtin_amdgcn_s_memrealtime();
+  const long long gs_mark = GS_NOW();
+#endif
   issue_loads(0);
   for (;;) {
+#ifdef GEMM_STAMPS
+    gs_t0 = GS_NOW();
+#endif
 #pragma unroll
     for (int i = 0; i < WM; i++)
 #pragma unroll
@@ -293,6 +310,14 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, int bid, int step, 
       __syncthreads();  // epilogue reuses the staging LDS
     }
 
+#ifdef GEMM_STAMPS
+    {
+      const long long t_ = GS_NOW();
+      gs_loop += t_ - gs_t0;
+      gs_t0 = t_;
+      gs_tiles++;
+    }
+#endif
     // the tile being finished, and (PERSIST) the next one: its first K slice is in flight during the epilogue
     const int em0 = m0, en0 = n0;
     bool more = false;
@@ -403,9 +428,22 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, int bid, int step, 
         }
       }
     }
+#ifdef GEMM_STAMPS
+    gs_epi += GS_NOW() - gs_t0;
+#endif
     if (!more) break;
     __syncthreads();  // every wave is done with its transpose slice before the staging buffers are refilled
   }
+#ifdef GEMM_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 4096) {
+    long long *q = gemm_stamps + blockIdx.x * 8;
+    q[1] = (long long)__builtin_amdgcn_s_memrealtime();
+    q[2] += gs_loop;
+    q[3] += gs_epi;
+    q[4] += gs_tiles;
+    q[5] = GS_NOW() - gs_mark;
+  }
+#endif
 }
 
 // MIXED: workgroups >= g.big_blocks compute 64x64 tiles of the rows [m_split, M) (same launch, same pipeline).
