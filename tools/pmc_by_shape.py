@@ -1,0 +1,60 @@
+"""Join the rocprofv3 --pmc passes of `bench.py --steps 1 --warmup 0 --no-secondary --no-cpu-baseline` with the
+launch-ordered GEMM shape list bench.py writes (SGIC_BENCH_SHAPES) -> per-shape HBM-side counter bytes per launch
+(FETCH_SIZE x2-corrected per MI355X_MICROARCH.md + WRITE_SIZE), next to the algorithmic bytes, plus the whole-step summary.
+usage: python tools/pmc_by_shape.py gpurun_out/pmcC gpurun_out/shapes.json profiles/round2_pmc_gemm_by_shape.json profiles/round2_pmc_gemm_summary.json"""
+import csv
+import glob
+import json
+import sys
+
+root, shapes_json, out_shape, out_sum = sys.argv[1:5]
+shapes = json.load(open(shapes_json))
+n = len(shapes)
+
+
+def load(tag, counter):
+    rows = []
+    for f in glob.glob(f"{root}_{tag}/**/*counter_collection.csv", recursive=True):
+        rows += [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and
+                 ("gemm_f32_kernel" in r["Kernel_Name"] or "conv3x3_thin" in r["Kernel_Name"])]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    return [float(r["Counter_Value"]) for r in rows[-n:]]
+
+
+fetch, write = load("FETCH_SIZE", "FETCH_SIZE"), load("WRITE_SIZE", "WRITE_SIZE")
+busy, act = load("MFMA", "SQ_VALU_MFMA_BUSY_CYCLES"), load("MFMA", "GRBM_GUI_ACTIVE")
+assert len(fetch) == len(write) == len(busy) == n, (len(fetch), len(write), len(busy), n)
+agg = {}
+for i, (key, fl, ms) in enumerate(shapes):
+    k = tuple(key[:3]) if key[0] != "batched" else tuple(key[2:5])
+    a = agg.setdefault(k, dict(calls=0, fetch=0.0, write=0.0, busy=0.0, act=0.0, ms=0.0, flops=0.0, res=bool(key[3]) if key[0] != "batched" else False))
+    a["calls"] += 1
+    a["fetch"] += fetch[i]
+    a["write"] += write[i]
+    a["busy"] += busy[i]
+    a["act"] += act[i]
+    a["ms"] += ms
+    a["flops"] += fl
+rows = []
+for (M, N, K), a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+    algo = 4.0 * (M * K + N * K + M * N * (2 if a["res"] else 1))
+    cnt = (2 * a["fetch"] + a["write"]) * 1024 / a["calls"]
+    rows.append({"shape": [M, N, K], "calls": a["calls"], "algorithmic_MB": round(algo / 1e6, 1), "counter_MB": round(cnt / 1e6, 1),
+                 "counter_over_algorithmic": round(cnt / algo, 2), "fetch_MB_x2": round(2 * a["fetch"] * 1024 / a["calls"] / 1e6, 1),
+                 "write_MB": round(a["write"] * 1024 / a["calls"] / 1e6, 1),
+                 "mfma_busy_fraction": round(a["busy"] / (a["act"] / 8 * 1024), 4) if a["act"] else None})
+json.dump({"command": "tools/pmc_collect.sh (three rocprofv3 --pmc passes over bench.py --steps 1 --warmup 0 --no-secondary --no-cpu-baseline) "
+                      "+ tools/pmc_by_shape.py", "note": "FETCH_SIZE doubled (gfx950 reports half of a wide coalesced stream); Infinity-Cache "
+                      "hits are counted; the Infinity Cache (256 MiB) holds the weights + activations of neighbouring launches, so counter bytes "
+                      "above the algorithmic bytes are L2 misses served on-die, not HBM re-reads", "shapes": rows}, open(out_shape, "w"), indent=1)
+fs, ws, bs, ga = sum(fetch), sum(write), sum(busy), sum(act)
+summ = {"command": "rocprofv3 --pmc <counter set> --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-secondary --no-cpu-baseline "
+                   "(three separate passes: FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE)",
+        "kernel": f"gemm_f32_kernel<...>: the {n} GEMM launches of the timed step", "launches": n,
+        "hbm_fetch_MB_per_launch_x2_corrected": round(2 * fs * 1024 / n / 1e6, 2), "hbm_write_MB_per_launch": round(ws * 1024 / n / 1e6, 2),
+        "algorithmic_MB_per_launch": round(sum(r["algorithmic_MB"] * r["calls"] for r in rows) / n, 2),
+        "SQ_VALU_MFMA_BUSY_CYCLES": bs, "GRBM_GUI_ACTIVE": ga, "mfma_busy_fraction": round(bs / (ga / 8 * 1024), 4) if ga else None}
+json.dump(summ, open(out_sum, "w"), indent=1)
+print(json.dumps(summ, indent=1))
+for r in rows[:12]:
+    print(r)

@@ -5,9 +5,10 @@ set -e
 MODE=${1:-compress}
 TAG=${2:-pmcC}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_FETCH_SIZE -- python3 bench.py --mode $MODE --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/${TAG}_f.log 2>&1
+ARGS="--mode $MODE --steps 1 --warmup 0 --no-cpu-baseline --no-secondary"
+SGIC_BENCH_SHAPES=gpurun_out/${TAG}_shapes.json rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_FETCH_SIZE -- python3 bench.py $ARGS > gpurun_out/${TAG}_f.log 2>&1
 echo fetch done
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${TAG}_WRITE_SIZE -- python3 bench.py --mode $MODE --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/${TAG}_w.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${TAG}_WRITE_SIZE -- python3 bench.py $ARGS > gpurun_out/${TAG}_w.log 2>&1
 echo write done
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${TAG}_MFMA -- python3 bench.py --mode $MODE --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/${TAG}_m.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${TAG}_MFMA -- python3 bench.py $ARGS > gpurun_out/${TAG}_m.log 2>&1
 echo mfma done
