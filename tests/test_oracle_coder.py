@@ -116,3 +116,19 @@ def test_resize_bicubic_matches_pillow():
         ref = np.asarray(Image.fromarray(img, "RGB").resize((ow, oh), Image.BICUBIC))
         got = orc.resize_bicubic_u8(np.ascontiguousarray(img.transpose(2, 0, 1)), oh, ow).transpose(1, 2, 0)
         assert np.array_equal(got, ref), (h, w, oh, ow)
+
+
+def test_oracle_coder_on_the_wide_reference_fixture(golden_dir):
+    """the C restatement of the coder against the 33 streams the REAL reference produced end to end
+    (tests/golden/streams_small.npz, oracle/gen_golden_streams.py): encode is byte-identical, decode returns the
+    reference's symbols (0 where the index says skip) and consumes the stream"""
+    import os
+    g = np.load(os.path.join(golden_dir, "streams_small.npz"))
+    t = np.load(os.path.join(golden_dir, "cdf_table.npz"))
+    tab = orc.Table(t["cdf"], t["cdf_length"], t["offset"])
+    for name in g["names"]:
+        sym, idx, ref = g[f"{name}.sym"].reshape(-1), g[f"{name}.idx"].reshape(-1), g[f"{name}.stream"].tobytes()
+        assert orc.rans_encode(sym, idx, tab) == ref, name
+        d = orc.Decoder(ref, tab)
+        assert np.array_equal(d.decode(idx), np.where(idx < 0, 0, sym)), name
+        assert orc.pack12(g[f"{name}.vq"]).endswith(b"\x40") or len(g[f"{name}.vq"]) % 2 == 1

