@@ -259,7 +259,8 @@ def test_gemm_fuzz_all_tile_modes_identical_and_close_to_fp64():
     old = ops.AUTOTUNE
     ops.AUTOTUNE = False
     try:
-        shapes = [(9248, 1024, 256), (289, 3072, 1024), (1600, 768, 96), (70000, 128, 128), (5000, 200, 64), (129, 132, 36)]
+        shapes = [(9248, 1024, 256), (289, 3072, 1024), (1600, 768, 96), (70000, 128, 128), (5000, 200, 64), (129, 132, 36),
+                  (9248, 4096, 128), (17440, 3072, 96), (20000, 1156, 64), (12345, 2052, 160)]   # several rounds of the 512 resident workgroups
         shapes += [(int(rng.integers(1, 3000)), int(rng.integers(1, 600)) * 4, int(rng.integers(1, 80)) * 4) for _ in range(10)]
         for (M, N, K) in shapes:
             a = torch.from_numpy(rng.standard_normal((M, K), dtype=np.float32)).to(dev)
