@@ -47,6 +47,13 @@ def load_state(path, spec_fn, cfg, seed):
     return W.synth_weights(spec_fn(cfg), seed=seed)
 
 
+def _write_outputs(c2df_path, blob, npy_path, vec):
+    """the two per-image files of compress.py:282-286; runs on the writer threads (file I/O releases the GIL)"""
+    with open(c2df_path, "wb") as f:
+        f.write(blob)
+    np.save(npy_path, vec)
+
+
 def stem_of(path):
     return os.path.splitext(os.path.basename(path))[0]
 
@@ -150,11 +157,15 @@ def main(argv=None):
             header = {"version": 2, "model_id": clip_meta["model_id"], "embed_dim": int(ccfg.embed_dim),
                       "quant_type": "u8_symmetric_-1_1", "image_hw": [int(batch.H), int(batch.W)],
                       "padding": [int(pl), int(pr), int(pt), int(pb)]}
-            with open(os.path.join(bit_dir, f"{stem}.c2df"), "wb") as f:
-                f.write(pack_c2df(enc, header))
-            np.save(os.path.join(clip_dir, f"{stem}.npy"), streams["clip_unit"])
             vecs[i] = streams["clip_unit"]
+            writes.append(io_pool.submit(_write_outputs, os.path.join(bit_dir, f"{stem}.c2df"), pack_c2df(enc, header),
+                                         os.path.join(clip_dir, f"{stem}.npy"), vecs[i].copy()))
+        while len(writes) > 4 * args.batch_size:      # bounded: file-system stalls push back on the producer
+            writes.popleft().result()
 
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    io_pool, writes = ThreadPoolExecutor(max_workers=4), deque()
     loader = None
     try:
         loader = ShardLoader(mine, args.batch_size, workers=args.workers, depth=args.prefetch)
@@ -170,11 +181,14 @@ def main(argv=None):
             pending = (h, batch, pad, copied)
         if pending is not None:
             write_out(pending)
+        while writes:
+            writes.popleft().result()             # every file is on disk before the index is assembled; errors surface here
     except BaseException as e:   # noqa: BLE001 -- reported below, after the collective the peers are waiting in
         failed = e
     finally:
         if loader is not None:
             loader.close()
+        io_pool.shutdown(wait=True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t_start
 
