@@ -167,6 +167,20 @@ def tile_of(key, dev=None):
 _load_tile_cache()
 
 
+def _save_at_exit():
+    """every entry point (CLIs, service, tools, bench) leaves its new measurements behind for the next process"""
+    try:
+        if _DIRTY:
+            save_tile_cache()
+    except Exception:   # noqa: BLE001 -- never turn a clean exit into a failing one
+        pass
+
+
+import atexit  # noqa: E402
+
+atexit.register(_save_at_exit)
+
+
 def _tune(key, launch):
     """two interleaved passes over the modes, best-of per mode: a single short sample mis-ranks modes that are within
     a few percent of each other (clock ramp, cold L2 after the previous mode's different tile walk)"""
