@@ -20,7 +20,7 @@ void set_error(const char *fmt, ...) {
 
 int main() {
   struct Shape { int M, N, K, res, act; } shapes[] = {{9248, 4096, 1024, 0, 1}, {9248, 1024, 4096, 1, 0}, {9248, 3072, 1024, 0, 0},
-                                                      {17440, 3072, 768, 0, 1}, {9248, 1024, 1024, 1, 0}, {1600, 768, 3072, 1, 0}};
+                                                      {17440, 3072, 768, 0, 1}, {9248, 1024, 1024, 1, 0}, {1600, 768, 3072, 1, 0}, {289, 1024, 1024, 1, 0}, {64, 64, 512, 0, 0}};
   const int modes[] = {1, 9, 11, 12, 13};
   for (auto sh : shapes) {
     float *A, *W, *C, *R, *bias;
