@@ -20,6 +20,7 @@ def load(root):
             if "attn_f32_kernel" not in r["Kernel_Name"]:
                 continue
             by.setdefault(int(r["Dispatch_Id"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
+            by[int(r["Dispatch_Id"])]["grid"] = float(r.get("Grid_Size", 0) or 0)
     return [by[k] for k in sorted(by)]
 
 
@@ -38,7 +39,11 @@ for sh in SHAPES:
         s = lambda g, k: sum(x.get(k, 0.0) for x in g)
         wc = s(g1, "SQ_WAVE_CYCLES")
         ga = s(g1, "GRBM_GUI_ACTIVE")
+        # waves of the MFMA items of one launch (ragged-row VALU workgroups issue no MFMA and are short): grid threads / 64
+        nwaves = sum(float(x.get("grid", 0)) for x in g1) / 64.0
+        life = 4.0 * wc / nwaves if nwaves else 0.0                    # SQ_WAVE_CYCLES counts quad-cycles: average wave lifetime
         e = {"mfma_busy_fraction": round(s(g1, "SQ_VALU_MFMA_BUSY_CYCLES") / (ga / 8 * 1024), 4) if ga else None,
+             "avg_wave_lifetime_cycles": round(life), "gui_active_cycles_per_launch": round(ga / 8 / len(g1)),
              "wave_time_parked_waitcnt_or_barrier": round(s(g1, "SQ_WAIT_ANY") / wc, 3) if wc else None,
              "wave_time_issue_stalled": round(s(g1, "SQ_WAIT_INST_ANY") / wc, 3) if wc else None,
              "wave_time_issuing": round(s(g1, "SQ_ACTIVE_INST_ANY") / wc, 3) if wc else None}
@@ -46,5 +51,15 @@ for sh in SHAPES:
             idx = s(g2, "SQ_LDS_IDX_ACTIVE")
             e["lds_bank_conflict_fraction"] = round(s(g2, "SQ_LDS_BANK_CONFLICT") / idx, 4) if idx else 0.0
         res["configs"][f"{sh}, attn_mode {m}"] = e
+# launch-span utilisation WITHOUT the profiler (tools/micro/attn_stamps.hip: s_memrealtime of the first wave's start and the last
+# wave's end, in-kernel clock from s_memtime / s_memrealtime = 2.08 GHz): MFMA cycles per SIMD / (span x clock)
+res["launch_span_utilisation_from_stamps"] = {
+    "method": "MFMA cycles per SIMD (items x key tiles x 64 MFMAs x 64 cycles / 1024 SIMDs) / (first-wave-start -> last-wave-end span "
+              "x 2.08 GHz), product build timed by tools/micro/attn_stamps.hip, no profiler attached",
+    "L=289 (attn_mode 5)": {"span_us": 120.0, "mfma_us_at_2.08GHz": 79.7, "utilisation": 0.66},
+    "L=545 (attn_mode 5)": {"span_us": 294.8, "mfma_us_at_2.08GHz": 213.4, "utilisation": 0.72},
+    "L=256 (attn_mode 1)": {"span_us": 70.5, "mfma_us_at_2.08GHz": 47.3, "utilisation": 0.67},
+    "note": "GRBM_GUI_ACTIVE-normalised figures above read lower because on dispatches this short GUI_ACTIVE also counts the "
+            "profiler's per-dispatch counter set-up / drain (176 k cycles for the L = 256 launch whose waves live 125 k)"}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
