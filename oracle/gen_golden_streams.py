@@ -8,6 +8,9 @@ h_bit_stream bytes the reference C++ coder produced, and the reference's y_hat (
 stream, compression_model.py:377-418).  The inputs are regenerated from the seeds (sgic_amd.data.synth_images).
 
 Run:  make -C oracle && python oracle/gen_golden_streams.py      -> tests/golden/streams_small.npz
+      python oracle/gen_golden_streams.py --large                -> tests/golden/streams_large.npz: two 256x256 images through
+      the PRODUCTION architecture (TiTok ViT-L, 24 layers, 768-wide detail branch) of the real reference, with z and h
+      kept as well, so the large model is pinned against the reference itself and not only against oracle/torch_ref.py
 """
 import os
 import sys
@@ -25,13 +28,14 @@ import torch  # noqa: E402
 
 import sgic_amd  # noqa: E402,F401
 from sgic_amd import weights as W  # noqa: E402
-from sgic_amd.config import SMALL  # noqa: E402
+from sgic_amd.config import LARGE, SMALL  # noqa: E402
 from sgic_amd.data import synth_images  # noqa: E402
 
 from entropy.compression_model import get_padding_size  # noqa: E402  (reference code)
 from models.codec_sq_fixbpp import Hybrid_Codec  # noqa: E402  (reference code)
 
-cfg = SMALL
+BIG = "--large" in sys.argv
+cfg = LARGE if BIG else SMALL
 torch.manual_seed(0)
 torch.set_num_threads(8)
 hc = Hybrid_Codec(wrap(cfg.titok_dict()), list(cfg.in_pos_enc), list(cfg.in_pos_dec), cfg.feat_dim, cfg.embed_dim, cfg.n_attn).eval()
@@ -44,6 +48,8 @@ bn.update(force=True)
 
 # (name, H, W, seed): 32 single-tile images, then the 16-tile worked geometry
 cases = [(f"s{i:02d}", 256, 256, 200 + i) for i in range(32)] + [("apple_geometry", 859, 1000, 300)]
+if BIG:
+    cases = [("L0", 256, 256, 400), ("L1", 256, 256, 401)]
 out = {"names": np.array([c[0] for c in cases]), "geometry": np.array([c[1:] for c in cases], dtype=np.int32)}
 for name, H, Wd, seed in cases:
     Hs, Ws = 256 * ((H + 255) // 256), 256 * ((Wd + 255) // 256)
@@ -76,7 +82,10 @@ for name, H, Wd, seed in cases:
     out[f"{name}.stream"] = np.frombuffer(stream, dtype=np.uint8).copy()
     out[f"{name}.y_hat"] = y_hat_dec.numpy()[0]
     out[f"{name}.h_hat_absmax"] = np.float32(h_hat.abs().max())
+    if BIG:
+        out[f"{name}.z"], out[f"{name}.h"], out[f"{name}.y"] = z.numpy(), h.numpy(), y.numpy()
     print(f"{name}: {H}x{Wd} -> {tuple(x.shape[2:])} tiles {stack} stream {len(stream)} B coded {int((idx >= 0).sum())}/{idx.numel()} "
           f"|sym|max {int(sym.abs().max())}", flush=True)
-np.savez_compressed(os.path.join(ROOT, "tests", "golden", "streams_small.npz"), **out)
-print("wrote tests/golden/streams_small.npz", os.path.getsize(os.path.join(ROOT, "tests", "golden", "streams_small.npz")), "bytes")
+dst = os.path.join(ROOT, "tests", "golden", "streams_large.npz" if BIG else "streams_small.npz")
+np.savez_compressed(dst, **out)
+print("wrote", dst, os.path.getsize(dst), "bytes")
