@@ -1,6 +1,8 @@
 """Decode-side golden vectors from the REAL reference modules (HybridDecoder, FeatMerge, taming Decoder,
 bottleneck.decompress) with synthetic weights, SMALL config; checks oracle/torch_ref.py on the spot.
-Build-container only.  Output: tests/golden/dec_small_<case>.npz.   Run after gen_golden_nn.py."""
+Build-container only.  Output: tests/golden/dec_small_<case>.npz.   Run after gen_golden_nn.py.
+With --large (after `gen_golden_streams.py --large`): the PRODUCTION architecture, decode_only of the two reference-made
+streams of tests/golden/streams_large.npz -> tests/golden/dec_large.npz (h_hat in full, stride-2 spatial samples of x_hat / titok / feat / latent)."""
 import os
 import sys
 
@@ -17,14 +19,15 @@ import torch  # noqa: E402
 
 import sgic_amd  # noqa: E402,F401
 from sgic_amd import weights as W  # noqa: E402
-from sgic_amd.config import SMALL  # noqa: E402
+from sgic_amd.config import LARGE, SMALL  # noqa: E402
 import torch_ref as TR  # noqa: E402
 
 from models.codec_sq_fixbpp import FeatMerge, Hybrid_Codec  # noqa: E402  (reference code)
 from taming.modules.diffusionmodules.model import Decoder as TamingDecoder  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
-cfg = SMALL
+BIG = "--large" in sys.argv
+cfg = LARGE if BIG else SMALL
 hc = Hybrid_Codec(wrap(cfg.titok_dict()), list(cfg.in_pos_enc), list(cfg.in_pos_dec), cfg.feat_dim, cfg.embed_dim, cfg.n_attn).eval()
 fm = FeatMerge(cfg.width, cfg.feat_dim, cfg.vq_n_embed).eval()
 td = TamingDecoder(**cfg.vqgan_ddconfig()).eval()
@@ -55,6 +58,27 @@ emb = sd["vqgan.quantize.embedding.weight"]
 bn = hc.quantize_feat
 bn.force_zero_thres = cfg.force_zero_thres
 bn.update(force=True)
+
+if BIG:
+    # production size: the two streams of streams_large.npz through the reference's decode_only, image by image
+    g = np.load(os.path.join(OUT, "streams_large.npz"))
+    T, outd = cfg.num_latent_tokens, {}
+    for name in [str(n) for n in g["names"]]:
+        idx = torch.from_numpy(g[f"{name}.vq"].astype(np.int32))
+        z_hat = hc.quantize.get_codebook_entry(idx).reshape(1, T, -1).permute(0, 2, 1).unsqueeze(2).contiguous()
+        z_hat = torch.nn.functional.normalize(z_hat, dim=1)
+        h_hat = bn.decompress(g[f"{name}.stream"].tobytes(), torch.Size([1, cfg.feat_dim, 8, 8]), 0)
+        titok, feat = hc.decoder(z_hat, h_hat, (1, 1))
+        logit = fm(titok, feat)
+        latent = torch.einsum("nchw,cd->ndhw", logit.softmax(1), emb)
+        x_hat = td(pqc(latent)).clamp(-1.0, 1.0)
+        outd[f"{name}.h_hat"], outd[f"{name}.x_hat_s2"] = h_hat.numpy(), x_hat[:, :, ::2, ::2].numpy()
+        outd[f"{name}.titok_s2"], outd[f"{name}.feat_s2"] = titok[:, :, ::2, ::2].numpy(), feat[:, :, ::2, ::2].numpy()
+        outd[f"{name}.latent_s2"] = latent[:, :, ::2, ::2].numpy()
+        print(f"{name}: x_hat range [{x_hat.min():.3f},{x_hat.max():.3f}] |titok|max {titok.abs().max():.2f} |latent|max {latent.abs().max():.2f}", flush=True)
+    np.savez_compressed(os.path.join(OUT, "dec_large.npz"), **outd)
+    print("wrote dec_large.npz", os.path.getsize(os.path.join(OUT, "dec_large.npz")))
+    sys.exit(0)
 
 for case in "abc":
     g = np.load(os.path.join(OUT, f"nn_small_{case}.npz"))

@@ -240,3 +240,33 @@ def test_large_architecture_vs_the_reference_itself(large, golden_dir):
         got = y_hat.view(8, 8, -1).permute(2, 0, 1).cpu().numpy()
         assert np.abs(got - ref).max() <= 2e-5 * max(1.0, float(np.abs(ref).max())), name
     print(f"LARGE vs the reference: {ident}/{B} streams byte-identical, {B}/{B} reference streams decode to the reference's y_hat")
+
+
+def test_large_architecture_decode_vs_the_reference_itself(large, golden_dir):
+    """Decode side at the production size against the REAL reference (oracle/gen_golden_dec.py --large): the reference's
+    decode_only of its own two streams (tests/golden/streams_large.npz) -- h_hat, and stride-2 samples of titok / feat /
+    latent / x_hat -- vs the HIP decode_batch of the same container fields.  Tolerances as tests/test_gpu_decoder.py at the
+    small size: intermediates within 5e-4 * max|ref|, pixels PSNR > 80 dB (measured ~110 dB)."""
+    import os
+    codec = large
+    g = np.load(os.path.join(golden_dir, "streams_large.npz"))
+    d = np.load(os.path.join(golden_dir, "dec_large.npz"))
+    from oracle import orc
+    for name in [str(n) for n in g["names"]]:
+        enc = {"z_bit_stream": orc.pack12(g[f"{name}.vq"]), "h_bit_stream": g[f"{name}.stream"].tobytes(), "img_shape": (256, 256),
+               "feat_shape": torch.Size([1, 768, 8, 8]), "stack_shape": (1, 1), "token_length": 32,
+               "z_indices_shape": torch.Size([1, 12, 1, 32])}
+        taps = {}
+        x_hat = codec.decode_batch([enc], taps=taps).cpu().numpy()
+        rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())
+        nchw = lambda t: t.cpu().numpy().reshape(1, 1, 1, 16, 16, t.shape[1]).transpose(0, 5, 1, 3, 2, 4).reshape(1, t.shape[1], 16, 16)
+        e = dict(h_hat=rel(taps["h_hat"].cpu().numpy().reshape(1, 8, 8, -1).transpose(0, 3, 1, 2), d[f"{name}.h_hat"]),
+                 titok=rel(nchw(taps["titok"])[:, :, ::2, ::2], d[f"{name}.titok_s2"]), feat=rel(nchw(taps["feat"])[:, :, ::2, ::2], d[f"{name}.feat_s2"]),
+                 latent=rel(nchw(taps["latent"])[:, :, ::2, ::2], d[f"{name}.latent_s2"]))
+        ref = d[f"{name}.x_hat_s2"]
+        mse = float(((x_hat[:, :, ::2, ::2] - ref) ** 2).mean())
+        psnr = 10 * np.log10(4.0 / max(mse, 1e-20))
+        print(f"LARGE decode vs the reference, {name}: rel err {{{', '.join(f'{k} {v:.1e}' for k, v in e.items())}}} "
+              f"max|dx| {float(np.abs(x_hat[:, :, ::2, ::2] - ref).max()):.1e} PSNR {psnr:.1f} dB")
+        assert all(v < 5e-4 for v in e.values()), e
+        assert psnr > 80.0
