@@ -138,3 +138,23 @@ def test_c2df_container_byte_identical_to_reference_sample(golden_dir):
     v = np.load(os.path.join(golden_dir, "ref_apple.npy"))
     assert np.array_equal(q, np.clip(np.round((v * 0.5 + 0.5) * 255.0), 0, 255).astype(np.uint8))
     assert zstd.decompress(zstd.Compressor(19).compress(q.tobytes())) == q.tobytes()
+
+
+def test_index_assembly_duplicate_stems_and_empty(tmp_path):
+    """two inputs that share a stem (a.jpg, a.png) collapse to ONE index entry, like their .npy files do in the reference
+    (compress.py:286 overwrites, :296 globs the survivors); an empty corpus writes no index at all (compress.py:297)"""
+    import sgic_amd  # noqa
+    from sgic_amd.compress import assemble_index
+    from sgic_amd.faiss_io import read_index_flat_ip
+    bit, idx = tmp_path / "bit", tmp_path / "idx"
+    bit.mkdir()
+    files = sorted(str(tmp_path / "in" / n) for n in ("a.jpg", "a.png", "b.jpg"))
+    for s in ("a", "b"):
+        (bit / f"{s}.c2df").write_bytes(b"x")
+    vecs = np.stack([_vec_of("a-jpg"), _vec_of("a-png"), _vec_of("b")])
+    ids = assemble_index(files, vecs, str(bit), str(idx), 16)
+    assert ids == [str(bit / "a.c2df"), str(bit / "b.c2df")]
+    v = read_index_flat_ip(str(idx / "index.faiss"))
+    assert v.shape == (2, 16) and np.allclose(v[0], _vec_of("a-png"), atol=1e-6)      # the later file in sorted order wins
+    assert assemble_index([], np.zeros((0, 16), np.float32), str(bit), str(tmp_path / "none"), 16) == []
+    assert not (tmp_path / "none").exists()

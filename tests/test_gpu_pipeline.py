@@ -134,3 +134,25 @@ def test_streaming_compress_equals_per_image_encode_only(tmp_path):
         assert tuple(enc["img_shape"]) == tuple(ref["img_shape"]) and hdr["padding"] == list(pad) and hdr["image_hw"] == [h, w]
         v = clipc.image_to_unit_vec(img[0])
         assert np.allclose(np.load(out / "clip_vecs" / f"f{i}.npy"), v, atol=1e-6), i
+
+
+def test_cli_edge_cases_empty_corpus_and_broken_file(tmp_path):
+    """an empty dataset directory is a clean no-op (no index written, like compress.py:297); a file that is not an image
+    fails the run loudly (in the header pass, before any GPU work) instead of hanging or writing a partial index"""
+    from PIL import Image
+    import sgic_amd  # noqa
+    from sgic_amd import compress
+    from sgic_amd.data import synth_images
+    empty, out0 = tmp_path / "empty", tmp_path / "out0"
+    empty.mkdir()
+    assert compress.main(["--dataset_dir", str(empty), "--save_dir", str(out0), "--small"]) == 0
+    assert not (out0 / "faiss" / "index.faiss").exists() and os.listdir(out0 / "bitstreams") == []
+    src, out1 = tmp_path / "src", tmp_path / "out1"
+    src.mkdir()
+    for i in range(3):
+        x = synth_images(1, 256, 256, 40 + i)[0]
+        Image.fromarray(((x * 0.5 + 0.5) * 255).round().byte().permute(1, 2, 0).numpy()).save(src / f"ok{i}.png")
+    (src / "zz_not_an_image.png").write_bytes(b"this is not a PNG")
+    with pytest.raises(Exception):
+        compress.main(["--dataset_dir", str(src), "--save_dir", str(out1), "--small", "--batch_size", "2"])
+    assert not (out1 / "faiss" / "index.faiss").exists()
