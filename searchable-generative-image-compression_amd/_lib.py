@@ -46,7 +46,17 @@ def require_gpu():
         raise RuntimeError("sgic_amd needs an MI355X (gfx950) GPU: the hot path is HIP-only, no CPU fallback")
 
 
+try:   # the raw HIP stream of torch's current stream without building a Stream object (8 us -> 0.3 us per launch)
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+    _get_device = torch._C._cuda_getDevice
+except AttributeError:   # a torch without the private hooks
+    _raw_stream = None
+
+
 def stream():
+    """HIP stream of torch's CURRENT stream on the current device (honours `with torch.cuda.stream(...)`)"""
+    if _raw_stream is not None:
+        return c_void_p(_raw_stream(_get_device()))
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
