@@ -117,7 +117,9 @@ int sgic_dequant_step(const int16_t *d_sym, const float *d_means, int ld_sm, flo
  *     per CU), 5..8 = 1..4 with a start-up stagger of the co-resident workgroups, 9 / 10 = MIXED: whole rounds of
  *     128x128 tiles for the bulk of the rows + 64x64 tiles for the remaining rows in the same launch (2 / 1 LDS
  *     buffers), 11 = persistent 128x128 (2 resident workgroups per CU walk the tile list), 12 = persistent MIXED,
- *     13 / 14 = 64x64 tiles as their own launch (2 / 1 buffers; small-M GEMMs).  Results are bitwise identical for
+ *     13 / 14 = 64x64 tiles as their own launch (2 / 1 buffers; small-M GEMMs), 15 = latency kernel for under-filled
+ *     launches (32x32 tiles of 16x16x4-MFMA blocks: 4x shorter dependent chains, 4x the workgroups; needs K % 64 == 0,
+ *     otherwise runs as 13).  Results are bitwise identical for
  *     every choice (the k order is fixed by K alone); the host autotuner (sgic_amd.ops) picks per shape and persists
  *     its picks.
  *   attn_mode (sgic_attention_f32): 0 = built-in choice, otherwise the number of 32-query-row waves per workgroup

@@ -480,12 +480,135 @@ __global__ __launch_bounds__(256, (WM == 1 && WN == 1) ? 4 : (NBUF == 1 ? 3 : 2)
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Latency variant for UNDER-FILLED launches (tile mode 15): single-image requests (M = 289 / 545 / 256 rows: the
+// reference's own compress.py loop calls encode_only with B = 1), the CLIP towers, the bottleneck.
+// With 64x64 tiles such a GEMM occupies a fraction of the chip (289 x 1024 -> 80 workgroups on 256 CUs) and every wave
+// walks the tile's whole K range as ONE dependent MFMA chain: K x 32 cycles, 14 us at K = 1024, whatever the grid.
+// Here a workgroup owns a 32x32 tile and each of its 4 waves a 16x16 block on v_mfma_f32_16x16x4_f32: 4 k per 32-cycle
+// issue, so the chain is K x 10 cycles (40-cycle dependent latency) and there are 4x the workgroups to fill the chip.
+// The k order is the one every other mode uses -- inside an 8-k group: 0,4,1,5 | 2,6,3,7 (lane group g = lane >> 4 of a
+// 16x16x4 MFMA is accumulated g = 0..3; the two MFMAs of a group take elements {0,2} / {1,3} of the float4 a lane holds
+// for k-half g & 1) -- and the result is BITWISE the same (tools/micro/mfma16_order.hip; tests: all modes equal).
+// Loads: K slices of 64 through a ring of three LDS buffers, requested three steps ahead and parked in two register
+// sets (a step is only ~0.3 us of MFMA, far less than a load's latency).  The W fragment is the MFMA's A operand, so a
+// lane ends up with 4 consecutive columns of one C row: the epilogue is a float4 store from registers.
+// ------------------------------------------------------------------------------------------------------------------
+#define LAT_BK 64
+#define LAT_LD 68   // 64 + 4 floats: 16-byte aligned rows, ds_read_b128 nearly conflict-free (one 2-way slot per group)
+
+template <int ACT, bool HASR>
+__device__ __forceinline__ void lat_store(const GemmArgs &g, const f32x4 &acc, int m, int n) {
+  if (m >= g.M || n >= g.N) return;
+  f32x4 v = acc;
+  if (g.bias) {
+    const f32x4 b = *reinterpret_cast<const f32x4 *>(g.bias + n);
+#pragma unroll
+    for (int t = 0; t < 4; t++) v[t] += b[t];
+  }
+#pragma unroll
+  for (int t = 0; t < 4; t++) v[t] = apply_act_c<ACT>(v[t]);
+  if constexpr (HASR) v += *reinterpret_cast<const f32x4 *>(g.R + (size_t)m * g.ldr + n);
+  const size_t crow = g.c_seg ? (size_t)(m / g.c_seg) * g.c_seg_stride + (m % g.c_seg) : (size_t)m;
+  *reinterpret_cast<f32x4 *>(g.C + crow * g.ldc + n) = v;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_lat16_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float sA[3][32 * LAT_LD];
+  __shared__ __attribute__((aligned(16))) float sB[3][32 * LAT_LD];
+  const int tiles_n = (g.N + 31) / 32;
+  const int m0 = ((int)blockIdx.x / tiles_n) * 32, n0 = ((int)blockIdx.x % tiles_n) * 32;   // n fastest: neighbours share A rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 16, wn = (wave & 1) * 16;
+  // staging map: a 32 x 64 slice is 512 float4 per operand: thread t moves float4 (row t >> 4, chunk t & 15) and row + 16
+  const int srow = tid >> 4, schunk = tid & 15;
+  const float *aptr[2], *wptr[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int am = min(m0 + srow + 16 * i, g.M - 1);
+    const size_t arow = g.a_seg ? (size_t)(am / g.a_seg) * g.a_seg_stride + (am % g.a_seg) : (size_t)am;
+    aptr[i] = g.A + arow * g.lda + schunk * 4;
+    wptr[i] = g.W + (size_t)min(n0 + srow + 16 * i, g.N - 1) * g.ldw + schunk * 4;
+  }
+  f32x4 qa[2][2], qb[2][2];
+  auto issue = [&](auto set_c, int k0) {
+    constexpr int S = decltype(set_c)::value;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      qa[S][i] = *reinterpret_cast<const f32x4 *>(aptr[i] + k0);
+      qb[S][i] = *reinterpret_cast<const f32x4 *>(wptr[i] + k0);
+    }
+  };
+  auto store = [&](auto set_c, int buf) {
+    constexpr int S = decltype(set_c)::value;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      *reinterpret_cast<f32x4 *>(&sA[buf][(srow + 16 * i) * LAT_LD + schunk * 4]) = qa[S][i];
+      *reinterpret_cast<f32x4 *>(&sB[buf][(srow + 16 * i) * LAT_LD + schunk * 4]) = qb[S][i];
+    }
+  };
+  const int r16 = lane & 15, grp = lane >> 4, khalf = grp & 1, hi = grp >> 1;
+  const int aoff = (wm + r16) * LAT_LD + khalf * 4, boff = (wn + r16) * LAT_LD + khalf * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  auto compute = [&](int buf) {   // 8 groups of 8 k: two MFMAs each, one dependent chain
+    f32x4 fa[8], fb[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+      fa[s] = *reinterpret_cast<const f32x4 *>(&sA[buf][aoff + s * 8]);
+      fb[s] = *reinterpret_cast<const f32x4 *>(&sB[buf][boff + s * 8]);
+    }
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hi ? fb[s][1] : fb[s][0], hi ? fa[s][1] : fa[s][0], acc, 0, 0, 0);   // k = 0,4,1,5
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hi ? fb[s][3] : fb[s][2], hi ? fa[s][3] : fa[s][2], acc, 0, 0, 0);   // k = 2,6,3,7
+    }
+  };
+  const int nk = g.K / LAT_BK;
+  // slice s is computed from LDS buffer s % 3; it was requested at step s - 3 into register set s & 1 and written at step s - 1
+  issue(IntC<0>{}, 0);
+  if (nk > 1) issue(IntC<1>{}, LAT_BK);
+  store(IntC<0>{}, 0);
+  if (nk > 2) issue(IntC<0>{}, 2 * LAT_BK);
+  __syncthreads();
+  int cur = 0;
+  auto step = [&](int kt, auto set_c) {   // set_c: the register set that holds slice kt + 1
+    const int nxt = cur == 2 ? 0 : cur + 1;
+    if (kt + 1 < nk) {
+      store(set_c, nxt);
+      if (kt + 3 < nk) issue(set_c, (kt + 3) * LAT_BK);
+    }
+    compute(cur);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    cur = nxt;
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    step(kt, IntC<1>{});
+    if (kt + 1 < nk) step(kt + 1, IntC<0>{});
+  }
+  // accumulator: C[m = tile row + wm + r16][n = tile col + wn + 4 grp + 0..3]
+  const int m = m0 + wm + r16, n = n0 + wn + 4 * grp;
+  auto run_act = [&](auto act_c) {
+    constexpr int ACT = decltype(act_c)::value;
+    if (g.R) lat_store<ACT, true>(g, acc, m, n);
+    else lat_store<ACT, false>(g, acc, m, n);
+  };
+  switch (g.act) {
+    case ACT_GELU: run_act(IntC<ACT_GELU>{}); break;
+    case ACT_SILU: run_act(IntC<ACT_SILU>{}); break;
+    case ACT_TANH: run_act(IntC<ACT_TANH>{}); break;
+    case ACT_LRELU: run_act(IntC<ACT_LRELU>{}); break;
+    default: run_act(IntC<ACT_NONE>{}); break;
+  }
+}
+
 // Launch options arrive per call (sgic_launch_opts, include/sgic.h): there is no process-global launch state.
 // tile_mode: 0 = heuristic; 1 = 128x128 / 2 LDS buffers, 2 = 128x64 / 2 buffers, 3 = 128x128 / 1 buffer, 4 = 128x64 / 1 buffer,
 // 5..8 = 1..4 with the start-up stagger, 9 = mixed 128x128 + 64x64 tail (2 buffers), 10 = mixed, 1 buffer,
 // 11 = persistent 128x128 (2 buffers, 2 workgroups per CU walk all tiles), 12 = persistent mixed,
-// 13 / 14 = 64x64 tiles as their own launch (2 / 1 buffers, 4+ workgroups per CU): small-M GEMMs (CLIP tower, bottleneck)
-#define SGIC_TILE_MODES 14
+// 13 / 14 = 64x64 tiles as their own launch (2 / 1 buffers, 4+ workgroups per CU): small-M GEMMs (CLIP tower, bottleneck),
+// 15 = latency kernel: 32x32 tiles of 16x16x4-MFMA blocks for under-filled launches (gemm_lat16_kernel)
+#define SGIC_TILE_MODES 15
 
 // Per-launch timing without extra packets on the stream: a launch that carries a profiler goes through
 // hipExtLaunchKernel with its own (start, stop) event pair, i.e. the timestamps are taken by the dispatch itself
@@ -584,6 +707,25 @@ static int gemm_launch(GemmArgs g, int batch, hipStream_t st, const sgic_launch_
     tiny = tile_mode >= 13;
   }
   const bool ktail = (K % BK) != 0;
+  // mode 15 / heuristic: the latency kernel, when the launch under-fills the chip even with 64x64 tiles (measured with C++
+  // launches, 64x64 kernel -> this one: 256x768x768 18.9 -> 11.4 us, 2048x128x256 8.5 -> 5.7 us, one 64x64x512 tile 12.9 ->
+  // 8.0 us, 289x1024x1024 24.5 -> 23.0 us; slower from ~240 workgroups of 64x64 up) and the operands meet its (float4,
+  // K % 64) requirements; anything else falls through to the ordinary modes
+  {
+    const bool lat_ok = batch == 1 && !g.conv_C && (K % LAT_BK) == 0 && g.vec_epilogue && (long)((M + 31) / 32) * ((N + 31) / 32) < (1 << 20);
+    const long wg64 = (long)((M + 63) / 64) * ((N + 63) / 64);
+    if (lat_ok && (tile_mode == 15 || (!tile_mode && wg64 <= 96))) {
+      const dim3 lgrid((unsigned)(((M + 31) / 32) * ((N + 31) / 32)));
+      if (const auto *evp = prof_next(o)) {
+        const auto &ev = *evp;
+        hipExtLaunchKernelGGL(gemm_lat16_kernel, lgrid, dim3(256), 0, st, ev.first, ev.second, 0, g);
+      } else {
+        gemm_lat16_kernel<<<lgrid, 256, 0, st>>>(g);
+      }
+      return sgic::check_launch("gemm_lat16_kernel");
+    }
+    if (tile_mode == 15) tile_mode = 13, tiny = true;   // not eligible: the 64x64 launch
+  }
   // heuristic for under-filled grids: when the 128-row tiling leaves more than half of the 256 CUs without a workgroup,
   // 64x64 tiles give 4x the workgroups and a 4x shorter serial MFMA chain per wave (the latency of small-M GEMMs)
   if (!tile_mode && !ktail && batch == 1 && (long)tm128 * ((N + (narrow ? 63 : 127)) / (narrow ? 64 : 128)) < 128) tiny = true;

@@ -81,7 +81,7 @@ def empty(*shape, like=None, dtype=torch.float32, device=None):
 #      save_tile_cache(); bench.py and the CLI drivers call it at exit).
 # AUTOTUNE = False uses the cache / built-in heuristic only.  Single-threaded by design (one launching thread).
 AUTOTUNE = True
-TUNE_MODES = (1, 2, 3, 4, 5, 7, 9, 10, 11, 12, 13, 14)   # {128x128, 128x64} x {double, single LDS buffer}, staggered wide, mixed 128x128 + 64x64 tail, persistent (plain, mixed), 64x64
+TUNE_MODES = (1, 2, 3, 4, 5, 7, 9, 10, 11, 12, 13, 14, 15)   # {128x128, 128x64} x {double, single LDS buffer}, staggered wide, mixed 128x128 + 64x64 tail, persistent (plain, mixed), 64x64, 16x16x4 latency kernel
 ATTN_MODES = (1, 2, 3, 4, 5, 6)                            # {single, double}-buffered K/V ring x start-up stagger {0, 4096, 8192} cycles
 _TILE = {}        # key -> mode (exact shapes)
 _FAMILY = {}      # key without M -> {M: mode}

@@ -10,7 +10,7 @@ from sgic_amd import ops
 
 dev = torch.device("cuda:0")
 ops.AUTOTUNE = False
-MODES = tuple(int(x) for x in os.environ.get("MODES", "1,2,3,4,5,7,9,10,11,12,13,14").split(","))
+MODES = tuple(int(x) for x in os.environ.get("MODES", "1,2,3,4,5,7,9,10,11,12,13,14,15").split(","))
 SHAPES = [(9248, 1024, 4096, 1), (9248, 4096, 1024, 0), (9248, 3072, 1024, 0), (17440, 3072, 768, 0), (17440, 768, 3072, 1),
           (8192, 3072, 768, 0), (8192, 768, 3072, 1), (17440, 2304, 768, 0), (9248, 1024, 1024, 1), (8192, 2304, 768, 0),
           (8192, 768, 768, 1), (17440, 768, 768, 1), (1600, 768, 3072, 1), (1600, 3072, 768, 0), (1600, 2304, 768, 0), (1600, 768, 768, 1), (2048, 768, 768, 0), (2048, 128, 256, 1),
