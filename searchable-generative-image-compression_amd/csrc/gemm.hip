@@ -488,14 +488,25 @@ __global__ __launch_bounds__(256, (WM == 1 && WN == 1) ? 4 : (NBUF == 1 ? 3 : 2)
 // Here a workgroup owns a 32x32 tile and each of its 4 waves a 16x16 block on v_mfma_f32_16x16x4_f32: 4 k per 32-cycle
 // issue, so the chain is K x 10 cycles (40-cycle dependent latency) and there are 4x the workgroups to fill the chip.
 // The k order is the one every other mode uses -- inside an 8-k group: 0,4,1,5 | 2,6,3,7 (lane group g = lane >> 4 of a
-// 16x16x4 MFMA is accumulated g = 0..3; the two MFMAs of a group take elements {0,2} / {1,3} of the float4 a lane holds
-// for k-half g & 1) -- and the result is BITWISE the same (tools/micro/mfma16_order.hip; tests: all modes equal).
+// 16x16x4 MFMA is accumulated g = 0..3; the LDS image of a slice is permuted so that each lane group reads its two k's as
+// one float2) -- and the result is BITWISE the same (tools/micro/mfma16_order.hip; tests: all modes equal).
 // Loads: K slices of 64 through a ring of three LDS buffers, requested three steps ahead and parked in two register
 // sets (a step is only ~0.3 us of MFMA, far less than a load's latency).  The W fragment is the MFMA's A operand, so a
 // lane ends up with 4 consecutive columns of one C row: the epilogue is a float4 store from registers.
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef LAT_SETS
+#define LAT_SETS 2   // K slices in flight per workgroup (register sets); 2..8 measured equal
+#endif
 #define LAT_BK 64
 #define LAT_LD 68   // 64 + 4 floats: 16-byte aligned rows, ds_read_b128 nearly conflict-free (one 2-way slot per group)
+
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void lat_for(F &&f) {   // f(IntC<0>) ... f(IntC<N-1>): compile-time indices for the register sets
+  if constexpr (I < N) {
+    f(IntC<I>{});
+    lat_for<N, I + 1>(f);
+  }
+}
 
 template <int ACT, bool HASR>
 __device__ __forceinline__ void lat_store(const GemmArgs &g, const f32x4 &acc, int m, int n) {
@@ -513,6 +524,7 @@ __device__ __forceinline__ void lat_store(const GemmArgs &g, const f32x4 &acc, i
   *reinterpret_cast<f32x4 *>(g.C + crow * g.ldc + n) = v;
 }
 
+template <int R>   // R register sets: R K-slices (16 KB each per workgroup) in flight
 __global__ __launch_bounds__(256, 2) void gemm_lat16_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float sA[3][32 * LAT_LD];
   __shared__ __attribute__((aligned(16))) float sB[3][32 * LAT_LD];
@@ -530,7 +542,7 @@ __global__ __launch_bounds__(256, 2) void gemm_lat16_kernel(GemmArgs g) {
     aptr[i] = g.A + arow * g.lda + schunk * 4;
     wptr[i] = g.W + (size_t)min(n0 + srow + 16 * i, g.N - 1) * g.ldw + schunk * 4;
   }
-  f32x4 qa[2][2], qb[2][2];
+  f32x4 qa[R][2], qb[R][2];
   auto issue = [&](auto set_c, int k0) {
     constexpr int S = decltype(set_c)::value;
 #pragma unroll
@@ -539,52 +551,66 @@ __global__ __launch_bounds__(256, 2) void gemm_lat16_kernel(GemmArgs g) {
       qb[S][i] = *reinterpret_cast<const f32x4 *>(wptr[i] + k0);
     }
   };
+  // LDS image of a slice row: every 8-k group is stored as [k0 k2 | k4 k6 | k1 k3 | k5 k7], so lane group grp of the 16x16x4
+  // MFMAs finds ITS two k's (one for each of the group's two MFMAs) as one aligned float2 at offset 2 * grp -- no per-lane
+  // element selection in the loop (it was 6 v_cndmask per MFMA), half the LDS read bytes, conflict-free ds_read_b64.
+  // A thread stages the float4 of chunk c = k 4c .. 4c+3: elements (0,2) go to position 2 * (c & 1), elements (1,3) to 4 + 2 * (c & 1).
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const int sgoff = (schunk >> 1) * 8 + 2 * (schunk & 1);
   auto store = [&](auto set_c, int buf) {
     constexpr int S = decltype(set_c)::value;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-      *reinterpret_cast<f32x4 *>(&sA[buf][(srow + 16 * i) * LAT_LD + schunk * 4]) = qa[S][i];
-      *reinterpret_cast<f32x4 *>(&sB[buf][(srow + 16 * i) * LAT_LD + schunk * 4]) = qb[S][i];
+      float *pa = &sA[buf][(srow + 16 * i) * LAT_LD + sgoff], *pb = &sB[buf][(srow + 16 * i) * LAT_LD + sgoff];
+      *reinterpret_cast<f32x2 *>(pa) = f32x2{qa[S][i][0], qa[S][i][2]};
+      *reinterpret_cast<f32x2 *>(pa + 4) = f32x2{qa[S][i][1], qa[S][i][3]};
+      *reinterpret_cast<f32x2 *>(pb) = f32x2{qb[S][i][0], qb[S][i][2]};
+      *reinterpret_cast<f32x2 *>(pb + 4) = f32x2{qb[S][i][1], qb[S][i][3]};
     }
   };
-  const int r16 = lane & 15, grp = lane >> 4, khalf = grp & 1, hi = grp >> 1;
-  const int aoff = (wm + r16) * LAT_LD + khalf * 4, boff = (wn + r16) * LAT_LD + khalf * 4;
+  const int r16 = lane & 15, grp = lane >> 4;
+  const int aoff = (wm + r16) * LAT_LD + 2 * grp, boff = (wn + r16) * LAT_LD + 2 * grp;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   auto compute = [&](int buf) {   // 8 groups of 8 k: two MFMAs each, one dependent chain
-    f32x4 fa[8], fb[8];
+    f32x2 fa[8], fb[8];
 #pragma unroll
     for (int s = 0; s < 8; s++) {
-      fa[s] = *reinterpret_cast<const f32x4 *>(&sA[buf][aoff + s * 8]);
-      fb[s] = *reinterpret_cast<const f32x4 *>(&sB[buf][boff + s * 8]);
+      fa[s] = *reinterpret_cast<const f32x2 *>(&sA[buf][aoff + s * 8]);
+      fb[s] = *reinterpret_cast<const f32x2 *>(&sB[buf][boff + s * 8]);
     }
 #pragma unroll
     for (int s = 0; s < 8; s++) {
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hi ? fb[s][1] : fb[s][0], hi ? fa[s][1] : fa[s][0], acc, 0, 0, 0);   // k = 0,4,1,5
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hi ? fb[s][3] : fb[s][2], hi ? fa[s][3] : fa[s][2], acc, 0, 0, 0);   // k = 2,6,3,7
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[s][0], fa[s][0], acc, 0, 0, 0);   // k = 0,4,1,5 by lane group
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[s][1], fa[s][1], acc, 0, 0, 0);   // k = 2,6,3,7
     }
   };
   const int nk = g.K / LAT_BK;
-  // slice s is computed from LDS buffer s % 3; it was requested at step s - 3 into register set s & 1 and written at step s - 1
+  // slice s is computed from LDS buffer s % 3; it was requested R + 1 steps earlier into register set s % R and written to
+  // LDS one step before its use, so R slices are always in flight behind the one being computed
   issue(IntC<0>{}, 0);
-  if (nk > 1) issue(IntC<1>{}, LAT_BK);
   store(IntC<0>{}, 0);
-  if (nk > 2) issue(IntC<0>{}, 2 * LAT_BK);
+  lat_for<R>([&](auto i_c) {   // slices 1 .. R (slice R goes into set 0, just freed)
+    constexpr int I = decltype(i_c)::value + 1;
+    if (I < nk) issue(IntC<I % R>{}, I * LAT_BK);
+  });
   __syncthreads();
   int cur = 0;
-  auto step = [&](int kt, auto set_c) {   // set_c: the register set that holds slice kt + 1
-    const int nxt = cur == 2 ? 0 : cur + 1;
-    if (kt + 1 < nk) {
-      store(set_c, nxt);
-      if (kt + 3 < nk) issue(set_c, (kt + 3) * LAT_BK);
-    }
-    compute(cur);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    cur = nxt;
-  };
-  for (int kt = 0; kt < nk; kt += 2) {
-    step(kt, IntC<1>{});
-    if (kt + 1 < nk) step(kt + 1, IntC<0>{});
+  for (int base = 0; base < nk; base += R) {
+    lat_for<R>([&](auto i_c) {
+      constexpr int I = decltype(i_c)::value;
+      const int kt = base + I;
+      if (kt < nk) {                                   // uniform
+        const int nxt = cur == 2 ? 0 : cur + 1;
+        if (kt + 1 < nk) {
+          store(IntC<(I + 1) % R>{}, nxt);              // slice kt + 1 lives in set (kt + 1) % R = (I + 1) % R (base % R == 0)
+          if (kt + 1 + R < nk) issue(IntC<(I + 1) % R>{}, (kt + 1 + R) * LAT_BK);
+        }
+        compute(cur);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur = nxt;
+      }
+    });
   }
   // accumulator: C[m = tile row + wm + r16][n = tile col + wn + 4 grp + 0..3]
   const int m = m0 + wm + r16, n = n0 + wn + 4 * grp;
@@ -718,9 +744,9 @@ static int gemm_launch(GemmArgs g, int batch, hipStream_t st, const sgic_launch_
       const dim3 lgrid((unsigned)(((M + 31) / 32) * ((N + 31) / 32)));
       if (const auto *evp = prof_next(o)) {
         const auto &ev = *evp;
-        hipExtLaunchKernelGGL(gemm_lat16_kernel, lgrid, dim3(256), 0, st, ev.first, ev.second, 0, g);
+        hipExtLaunchKernelGGL(gemm_lat16_kernel<LAT_SETS>, lgrid, dim3(256), 0, st, ev.first, ev.second, 0, g);
       } else {
-        gemm_lat16_kernel<<<lgrid, 256, 0, st>>>(g);
+        gemm_lat16_kernel<LAT_SETS><<<lgrid, 256, 0, st>>>(g);
       }
       return sgic::check_launch("gemm_lat16_kernel");
     }
