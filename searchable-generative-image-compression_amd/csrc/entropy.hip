@@ -136,10 +136,8 @@ __global__ __launch_bounds__(256) void rans_encode_kernel(const int16_t *__restr
                                                           const int32_t *__restrict__ offsets, int rows, int cols,
                                                           uint8_t *__restrict__ out, int cap, int32_t *d_off,
                                                           int32_t *d_len, int32_t *d_err) {
-  __shared__ uint32_t s_sf[ENC_CHUNK];   // start | freq<<16
-  __shared__ uint32_t s_rcp[ENC_CHUNK];  // reciprocal
-  __shared__ uint32_t s_raw[ENC_CHUNK];  // RAW_SKIP / RAW_NONE / bypass raw value
-  __shared__ uint8_t s_shift[ENC_CHUNK];
+  // one 16-byte record per symbol: {start | freq << 16, reciprocal, RAW_SKIP / RAW_NONE / bypass raw value, shift}
+  __shared__ __attribute__((aligned(16))) uint4 s_rec[ENC_CHUNK];
   __shared__ int s_bad;
   const int b = blockIdx.x, tid = threadIdx.x;
   sym += (size_t)b * n;
@@ -147,7 +145,7 @@ __global__ __launch_bounds__(256) void rans_encode_kernel(const int16_t *__restr
   uint8_t *slot = out + (size_t)b * cap;
   if (tid == 0) s_bad = 0;
   uint32_t x = RANS_L;
-  int ptr = cap;  // bytes slot[ptr..cap) are written; thread 0 only
+  int ptr = cap;  // bytes slot[ptr..cap) are written; carried (uniformly) by every lane of wave 0
   int err = 0;
   __syncthreads();
 
@@ -184,17 +182,26 @@ __global__ __launch_bounds__(256) void rans_encode_kernel(const int16_t *__restr
           }
         }
       }
-      s_sf[t] = sf;
-      s_rcp[t] = rcp;
-      s_raw[t] = raw;
-      s_shift[t] = (uint8_t)sh;
+      s_rec[t] = make_uint4(sf, rcp, raw, sh);
     }
     __syncthreads();
-    if (tid == 0 && !err && !s_bad) {
+    // Phase B on the SCALAR unit: wave 0 runs the recurrence with uniform control flow -- every lane carries the same
+    // (x, ptr, err), the record of the NEXT symbol is requested while the current one is folded in (one broadcast
+    // ds_read_b128 per symbol instead of four dependent reads), its fields are moved to SGPRs (readfirstlane) so the state
+    // update is s_mul_hi / s_lshr / s_add, and only lane 0 stores the bytes.  (As a single lane on the vector unit this
+    // loop cost ~500 cycles per symbol: 0.9 ms for one image, serial on the critical path of a single-image request.)
+    if (tid < 64 && !err && !s_bad) {
+      const bool l0 = tid == 0;
+      // scalar copies: readfirstlane tells the compiler the state is wave-uniform, so the recurrence compiles to SALU
+      uint32_t xs = __builtin_amdgcn_readfirstlane(x);
+      int ps = __builtin_amdgcn_readfirstlane(ptr);
+      uint4 rec_n = s_rec[cnt - 1];
       for (int t = cnt - 1; t >= 0; --t) {
-        const uint32_t raw = s_raw[t];
+        const uint4 rec = rec_n;
+        rec_n = s_rec[t > 0 ? t - 1 : 0];
+        const uint32_t raw = __builtin_amdgcn_readfirstlane(rec.z);
         if (raw == RAW_SKIP) continue;
-        if (ptr < 48) {  // worst case for one symbol: 11 bypass entries + 1 symbol < 16 bytes (+ flush/flag)
+        if (ps < 48) {  // worst case for one symbol: 11 bypass entries + 1 symbol < 16 bytes (+ flush/flag)
           err = SGIC_ENOSPC;
           break;
         }
@@ -204,32 +211,37 @@ __global__ __launch_bounds__(256) void rans_encode_kernel(const int16_t *__restr
           while ((raw >> (2 * nb)) != 0) ++nb;
           for (int j = nb - 1; j >= 0; --j) {
             const uint32_t v = (raw >> (2 * j)) & 3u;
-            while (x >= (1u << 29)) {
-              slot[--ptr] = (uint8_t)x;
-              x >>= 8;
+            while (xs >= (1u << 29)) {
+              --ps;
+              if (l0) slot[ps] = (uint8_t)xs;
+              xs >>= 8;
             }
-            x = (x << 2) | v;
+            xs = (xs << 2) | v;
           }
           const int n3 = nb / 3, rem = nb - 3 * n3;
           for (int j = 0; j <= n3; ++j) {
             const uint32_t v = (j == 0) ? (uint32_t)rem : 3u;
-            while (x >= (1u << 29)) {
-              slot[--ptr] = (uint8_t)x;
-              x >>= 8;
+            while (xs >= (1u << 29)) {
+              --ps;
+              if (l0) slot[ps] = (uint8_t)xs;
+              xs >>= 8;
             }
-            x = (x << 2) | v;
+            xs = (xs << 2) | v;
           }
         }
-        const uint32_t sf = s_sf[t], freq = sf >> 16, start = sf & 0xffffu;
+        const uint32_t sf = __builtin_amdgcn_readfirstlane(rec.x), freq = sf >> 16, start = sf & 0xffffu;
         const uint32_t x_max = freq << 15;
-        while (x >= x_max) {
-          slot[--ptr] = (uint8_t)x;
-          x >>= 8;
+        while (xs >= x_max) {
+          --ps;
+          if (l0) slot[ps] = (uint8_t)xs;
+          xs >>= 8;
         }
-        const uint32_t q = __umulhi(x, s_rcp[t]) >> s_shift[t];
+        const uint32_t q = __umulhi(xs, __builtin_amdgcn_readfirstlane(rec.y)) >> __builtin_amdgcn_readfirstlane(rec.w);
         const uint32_t bias = (freq < 2) ? start + 65535u : start;
-        x = x + bias + q * (65536u - freq);
+        xs = xs + bias + q * (65536u - freq);
       }
+      x = xs;
+      ptr = ps;
     }
     __syncthreads();
   }
