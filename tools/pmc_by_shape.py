@@ -16,7 +16,7 @@ def load(tag, counter):
     rows = []
     for f in glob.glob(f"{root}_{tag}/**/*counter_collection.csv", recursive=True):
         rows += [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and
-                 ("gemm_f32_kernel" in r["Kernel_Name"] or "conv3x3_thin" in r["Kernel_Name"])]
+                 any(k in r["Kernel_Name"] for k in ("gemm_f32_kernel", "gemm_lat16_kernel", "conv3x3_thin"))]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     return [float(r["Counter_Value"]) for r in rows[-n:]]
 
