@@ -48,8 +48,9 @@ def profile_end():
     return [(fl, float(buf[i]), key) for i, (fl, key) in enumerate(recs)]
 
 
-def _opts(tile=0, attn=0):
-    return launch_opts(tile, attn, _PROFILER if PROFILE is not None else None)
+def _opts(tile=0, attn=0, prof=None):
+    """prof: an explicit profiler handle (the tuner's probes); default: the bench's window when one is open"""
+    return launch_opts(tile, attn, prof if prof is not None else (_PROFILER if PROFILE is not None else None))
 
 
 def _rows(t):
@@ -181,20 +182,55 @@ import atexit  # noqa: E402
 atexit.register(_save_at_exit)
 
 
+_TUNE_PROF = None
+
+
+def _tune_profiler():
+    """a profiler handle of the tuner's own (the bench's window must not see the probes)"""
+    global _TUNE_PROF
+    if _TUNE_PROF is None:
+        h = ctypes.c_void_p(0)
+        check(lib.sgic_profiler_create(ctypes.byref(h)), "sgic_profiler_create")
+        _TUNE_PROF = h
+    return _TUNE_PROF
+
+
 def _tune(key, launch):
     """two interleaved passes over the modes, best-of per mode: a single short sample mis-ranks modes that are within
-    a few percent of each other (clock ramp, cold L2 after the previous mode's different tile walk)"""
+    a few percent of each other (clock ramp, cold L2 after the previous mode's different tile walk).
+    Short launches are timed by the DISPATCH's own timestamps (sgic_profiler: hipExtLaunchKernel start / stop events), i.e.
+    the kernel's duration alone: host-side event pairs around Python-issued launches cannot rank kernels shorter than the
+    ~13 us a launch costs on the host, which is every GEMM of a single-image request."""
+    prof = _tune_profiler()
+    reps = 3
     times = {}
     for _ in range(2):
-        for mode in TUNE_MODES:
-            launch(mode)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(4):
+        if M_big(key):
+            # launches of >= ~50 us: host-side event pairs around four back-to-back launches, which also charge a mode for
+            # what it costs BETWEEN kernels (the ramp of 512 persistent workgroups, the drain); measured better in the model
+            for mode in TUNE_MODES:
                 launch(mode)
-            e1.record()
-            e1.synchronize()
-            t = e0.elapsed_time(e1)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(4):
+                    launch(mode)
+                e1.record()
+                e1.synchronize()
+                t = e0.elapsed_time(e1)
+                times[mode] = min(t, times.get(mode, t))
+            continue
+        check(lib.sgic_profiler_begin(prof, len(TUNE_MODES) * reps), "sgic_profiler_begin")
+        for mode in TUNE_MODES:
+            launch(mode)                               # warm, untimed
+            for _ in range(reps):
+                launch(mode, prof)
+        buf = (ctypes.c_float * (len(TUNE_MODES) * reps))()
+        n = ctypes.c_int(0)
+        check(lib.sgic_profiler_end(prof, buf, len(TUNE_MODES) * reps, ctypes.byref(n)), "sgic_profiler_end")
+        if n.value != len(TUNE_MODES) * reps:
+            raise RuntimeError(f"tile tuner: {n.value} timed launches, expected {len(TUNE_MODES) * reps}")
+        for i, mode in enumerate(TUNE_MODES):
+            t = min(buf[i * reps + r] for r in range(reps))
             times[mode] = min(t, times.get(mode, t))
     order = sorted(times, key=times.get)
     best = order[0]
@@ -290,9 +326,9 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(
     if bias is not None:
         assert bias.shape == (N,) and bias.is_contiguous()
 
-    def launch(mode):
+    def launch(mode, prof=None):
         call("sgic_gemm_f32", _p(a), lda, _p(w), ldw, _p(bias), _p(residual), ldr, _p(out), ldc, M, N, K, act,
-             a_seg[0], a_seg[1], c_seg[0], c_seg[1], _opts(tile=mode))
+             a_seg[0], a_seg[1], c_seg[0], c_seg[1], _opts(tile=mode, prof=prof))
 
     if tile is not None:
         launch(tile)
@@ -520,9 +556,9 @@ def conv3x3(x_halo, w, bias, B, H, W, Cin, Cout, residual=None, act=ACT_NONE, ou
     if residual is not None:
         residual, ldr = _rows(residual)
 
-    def launch(mode):
+    def launch(mode, prof=None):
         call("sgic_conv3x3_f32", _p(x_halo), _p(w), _p(bias), _p(residual), ldr, _p(out), ldc, B, H, W, Cin, Cout, act,
-             _opts(tile=mode))
+             _opts(tile=mode, prof=prof))
 
     if tile is not None:
         launch(tile)
