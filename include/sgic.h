@@ -206,6 +206,23 @@ int sgic_clip_preprocess(const float *d_x, long img_stride, long ch_stride, int 
 /* unit-normalise rows + u8 quantise (compress.py:73,77). */
 int sgic_l2norm_u8(const float *d_x, int ldx, int M, int D, float *d_unit, uint8_t *d_q, sgic_stream_t stream);
 
+/* ---- fp32-accurate GEMM on the bf16 matrix pipe ("bf16x3" operand split; csrc/gemm_split.hip) -------------------
+ * Same contract as sgic_gemm_f32 (the nn.Linear / 1x1 Conv2d call sites cited there), computed as six bf16 MFMAs per
+ * 16 k over operands pre-split into three bf16 planes, x = x1 + x2 + x3 exactly.  Error vs an fp64 reference is at the
+ * level of (measured: slightly below) a plain fp32 fmaf chain; results are bitwise independent of M, of the tile mode
+ * and of the batch (fixed arithmetic order per output element), but NOT bitwise equal to sgic_gemm_f32's.
+ * sgic_split3_f32: x[rows, cols] fp32 (row map as A of sgic_gemm_f32) -> d_planes [3][rows][cols] bf16 bit patterns;
+ *   cols % 8 == 0.  Weights are split once at load time.
+ * sgic_gemm_split3_f32: d_A != NULL: A is split into the caller's workspace d_Aplanes (3*M*K uint16) first;
+ *   d_A == NULL: d_Aplanes already holds the planes.  K % 32 == 0.
+ *   opts->tile_mode: 0 = heuristic, 1 = 128x256, 2 = 128x128, 3 = 64x64 workgroup tiles. */
+int sgic_split3_f32(const float *d_x, int ld, int rows, int cols, int seg, int seg_stride, uint16_t *d_planes,
+                    sgic_stream_t stream);
+int sgic_gemm_split3_f32(const float *d_A, int lda, int a_seg, int a_seg_stride, uint16_t *d_Aplanes,
+                         const uint16_t *d_Wplanes, const float *d_bias, const float *d_R, int ldr, float *d_C, int ldc,
+                         int M, int N, int K, int act, int c_seg, int c_seg_stride, const sgic_launch_opts *opts,
+                         sgic_stream_t stream);
+
 /* Batched GEMM (element strides, 0 = shared operand) -- VQGAN AttnBlock single-head attention as
  * S_b = Q_b K_b^T, O_b = P_b V_b (taming/modules/diffusionmodules/model.py:168-192). */
 int sgic_gemm_batched_f32(const float *d_A, int lda, long strideA, const float *d_W, int ldw, long strideW,

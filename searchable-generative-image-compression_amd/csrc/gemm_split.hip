@@ -1,0 +1,327 @@
+// fp32-accurate GEMM on the bf16 matrix pipe ("bf16x3" operand split):  C[M,N] = epilogue( A[M,K] . W[N,K]^T )
+//
+// The fp32-input MFMA (gemm.hip) runs at 1/16 of the bf16 MFMA rate on CDNA4 and gfx950 has no xf32/TF32 mode.  Here
+// each fp32 operand is written as the exact sum of three bf16 values,  x = x1 + x2 + x3  (x1 = bf16(x),
+// x2 = bf16(x - x1), x3 = bf16(x - x1 - x2); 3 x 8 significant bits carry all 24 bits of an fp32), and a product as
+//     a.w  ~=  a1 w1 + (a1 w2 + a2 w1) + (a2 w2 + a1 w3 + a3 w1),
+// six v_mfma_f32_32x32x16_bf16 (fp32 accumulate; each bf16 x bf16 product is exact in fp32) for every 16 k instead of eight
+// fp32 MFMAs: 6/16 of the matrix-pipe time.  The dropped terms (a2 w3, a3 w2, a3 w3) are <= 2^-26 of the product, a
+// quarter of an fp32 ulp.  Measured against an fp64 reference (tools/micro/split3_gemm.hip, K = 4096, random normal
+// data): rms error 1.01e-6 of rms(C) vs 1.14e-6 for the plain fp32 fmaf chain that gemm.hip (and any fp32 GEMM)
+// computes -- this is an fp32 GEMM in accuracy, not a reduced-precision one; tests/test_gpu_split3.py holds that bound.
+//
+// Per output element the arithmetic is a fixed sequence fixed by K alone (k slices of 32 in order, the six terms in the
+// order above inside each 16 k): no split-K, and the same for every tile shape below, so results are bitwise independent
+// of M, of the tile choice and of the batch a row sits in (batch-invariant), like gemm.hip.
+//
+// Operands arrive PRE-SPLIT as three bf16 planes [3][rows][K]: weights once at load time, activations by
+// split3_rows_kernel (or directly by the producing kernel).  The GEMM kernel is then a pure bf16 pipeline:
+//  * tile (32 WM WAVES_M) x (32 WN WAVES_N), K slices of 32, two LDS stages; rows are 64 B (32 k) unpadded, the 16-byte
+//    slot of a row is XOR-swizzled with (row >> 2) & 3: conflict-free for the ds_read_b128 lane groups
+//    {0-3,12-15,20-27},... and for ds_write_b128;
+//  * global -> VGPR -> LDS staging one slice ahead (loads issued two slices ahead), one barrier per slice; MFMA fragments
+//    double-buffered in registers; LDS writes / global loads / fragment reads interleaved one per MFMA
+//    (sched_group_barrier);
+//  * XCD-aware grouped tile walk as in gemm.hip.
+#include <type_traits>
+
+#include "common.h"
+#include "gemm_act.h"
+#include "profiler.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned s3_pk_bf16(float lo, float hi) {   // v_cvt_pk_bf16_f32: round to nearest even
+  bf16x2 r = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, r);
+}
+// (x0, x1) -> the three bf16 pairs; the residuals are exact in fp32 (each step removes the leading 8 bits)
+__device__ __forceinline__ void s3_split_pair(float x0, float x1, unsigned &p1, unsigned &p2, unsigned &p3) {
+  p1 = s3_pk_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(p1 << 16), r1 = x1 - __uint_as_float(p1 & 0xffff0000u);
+  p2 = s3_pk_bf16(r0, r1);
+  const float s0 = r0 - __uint_as_float(p2 << 16), s1 = r1 - __uint_as_float(p2 & 0xffff0000u);
+  p3 = s3_pk_bf16(s0, s1);
+}
+
+// x[rows, cols] fp32 (row map as sgic_gemm_f32's A operand) -> planes [3][rows][cols] bf16; 8 elements per thread
+__global__ __launch_bounds__(256) void split3_rows_kernel(const float *__restrict__ x, int ld, int rows, int cols, int seg,
+                                                          int seg_stride, unsigned short *__restrict__ planes) {
+  const int c8 = cols >> 3;
+  const long total = (long)rows * c8, plane = (long)rows * cols;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int r = (int)(i / c8), c = (int)(i - (long)r * c8) * 8;
+    const size_t src = (seg ? (size_t)(r / seg) * seg_stride + (r % seg) : (size_t)r) * ld + c;
+    const f32x4 v0 = *reinterpret_cast<const f32x4 *>(x + src), v1 = *reinterpret_cast<const f32x4 *>(x + src + 4);
+    unsigned p1[4], p2[4], p3[4];
+    s3_split_pair(v0[0], v0[1], p1[0], p2[0], p3[0]);
+    s3_split_pair(v0[2], v0[3], p1[1], p2[1], p3[1]);
+    s3_split_pair(v1[0], v1[1], p1[2], p2[2], p3[2]);
+    s3_split_pair(v1[2], v1[3], p1[3], p2[3], p3[3]);
+    const size_t dst = (size_t)r * cols + c;
+    *reinterpret_cast<u32x4 *>(planes + dst) = u32x4{p1[0], p1[1], p1[2], p1[3]};
+    *reinterpret_cast<u32x4 *>(planes + plane + dst) = u32x4{p2[0], p2[1], p2[2], p2[3]};
+    *reinterpret_cast<u32x4 *>(planes + 2 * plane + dst) = u32x4{p3[0], p3[1], p3[2], p3[3]};
+  }
+}
+
+struct S3Args {
+  const unsigned short *A, *W;   // planes [3][M][K], [3][N][K]
+  const float *bias, *R;
+  float *C;
+  int M, N, K, ldr, ldc, act;
+  int c_seg, c_seg_stride;
+  long a_plane, w_plane;         // elements between planes
+};
+
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void gemm_split3_kernel(S3Args g) {
+  constexpr int NT = 64 * WAVES_M * WAVES_N, TM = 32 * WM * WAVES_M, TN = 32 * WN * WAVES_N;
+  constexpr int CA = TM * 4 / NT, CW = TN * 4 / NT;   // 16-byte chunks per thread, plane and stage
+  static_assert(CA * NT == TM * 4 && CW * NT == TN * 4 && CA >= 1 && CW >= 1, "tile / thread count");
+  constexpr int APLANE = TM * 64, WPLANE = TN * 64, STAGE = 3 * (APLANE + WPLANE);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN, nwg = tiles_m * tiles_n;
+  int m0, n0;
+  {   // XCD-aware bijective remap + grouped walk (8 m-tiles x all n-tiles, m fastest), as gemm.hip
+    int t = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = t & 7, within = t >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    const int per_group = 8 * tiles_n, group = t / per_group, first_m = group * 8, gsz = min(tiles_m - first_m, 8),
+              in_group = t - group * per_group;
+    m0 = (first_m + in_group % gsz) * TM;
+    n0 = (in_group / gsz) * TN;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave / WAVES_N) * (32 * WM), wn = (wave % WAVES_N) * (32 * WN);
+  // staging map: chunk (row = tid >> 2 + i NT/4, slot = tid & 3); NT/4 is a multiple of 16, so the swizzle term of a row
+  // does not depend on i
+  const int srow = tid >> 2, sslot = tid & 3;
+  const int sw = srow * 64 + ((sslot ^ ((srow >> 2) & 3)) * 16);
+  const unsigned short *aptr[CA], *wptr[CW];
+#pragma unroll
+  for (int i = 0; i < CA; i++) aptr[i] = g.A + (size_t)min(m0 + srow + i * (NT / 4), g.M - 1) * g.K + sslot * 8;
+#pragma unroll
+  for (int i = 0; i < CW; i++) wptr[i] = g.W + (size_t)min(n0 + srow + i * (NT / 4), g.N - 1) * g.K + sslot * 8;
+  u32x4 ra[3][CA], rw[3][CW];
+  auto issue = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+#pragma unroll
+      for (int i = 0; i < CA; i++) ra[p][i] = *reinterpret_cast<const u32x4 *>(aptr[i] + p * g.a_plane + k0);
+#pragma unroll
+      for (int i = 0; i < CW; i++) rw[p][i] = *reinterpret_cast<const u32x4 *>(wptr[i] + p * g.w_plane + k0);
+    }
+  };
+  auto store = [&](int buf) {
+    unsigned char *base = smem + buf * STAGE + sw;
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+#pragma unroll
+      for (int i = 0; i < CA; i++) *reinterpret_cast<u32x4 *>(base + p * APLANE + i * (NT / 4) * 64) = ra[p][i];
+#pragma unroll
+      for (int i = 0; i < CW; i++) *reinterpret_cast<u32x4 *>(base + 3 * APLANE + p * WPLANE + i * (NT / 4) * 64) = rw[p][i];
+    }
+  };
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; i++)
+#pragma unroll
+    for (int j = 0; j < WN; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+  const int lrow = lane & 31, lhalf = lane >> 5;
+  const int lsw = (lhalf ^ ((lrow >> 2) & 3)) * 16;   // slot of sub-step 0 (k 0..15 of the slice); sub-step 1 = this ^ 32
+  const int aoff = (wm + lrow) * 64 + lsw, boff = 3 * APLANE + (wn + lrow) * 64 + lsw;
+  struct Frag {
+    bf16x8 a[3][WM], b[3][WN];
+  };
+  auto read_frag = [&](Frag &f, int buf, int s) {
+    const unsigned char *base = smem + buf * STAGE;
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+#pragma unroll
+      for (int i = 0; i < WM; i++) f.a[p][i] = *reinterpret_cast<const bf16x8 *>(base + p * APLANE + ((aoff + i * 32 * 64) ^ (s * 32)));
+#pragma unroll
+      for (int j = 0; j < WN; j++) f.b[p][j] = *reinterpret_cast<const bf16x8 *>(base + p * WPLANE + ((boff + j * 32 * 64) ^ (s * 32)));
+    }
+  };
+  auto mfma_frag = [&](const Frag &f) {   // the six terms, smallest first; THE order of the arithmetic (see the header)
+#pragma unroll
+    for (int i = 0; i < WM; i++)
+#pragma unroll
+      for (int j = 0; j < WN; j++) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[2][i], f.b[0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0][i], f.b[2][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1][i], f.b[1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1][i], f.b[0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0][i], f.b[1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0][i], f.b[0][j], acc[i][j], 0, 0, 0);
+      }
+  };
+  const int nk = g.K / 32;
+  Frag f0, f1;
+  issue(0);
+  store(0);
+  if (nk > 1) issue(32);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  read_frag(f0, 0, 0);
+  // one K slice: [LDS writes of slice kt+1 | global loads of slice kt+2 | fragment reads of sub-step 1], one of each per MFMA
+  // of sub-step 0; barrier (LDS traffic only: the global loads stay in flight); the next slice's first fragments one per
+  // MFMA of sub-step 1
+  constexpr int NMF = WM * WN * 6, NLW = 3 * (CA + CW), NFR = 3 * (WM + WN);
+  auto stage = [&](int kt, auto store_c, auto issue_c) {
+    constexpr bool ST = decltype(store_c)::value, IS = decltype(issue_c)::value;
+    const int cur = kt & 1, nxt = cur ^ 1;
+    if constexpr (ST) store(nxt);
+    if constexpr (IS) issue((kt + 2) * 32);
+    read_frag(f1, cur, 1);
+    mfma_frag(f0);
+#pragma unroll
+    for (int i = 0; i < NMF; i++) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                 // MFMA
+      if (ST && i < NLW) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                              // DS write
+      if (i < NFR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                    // DS read
+      if (IS && i >= (NLW < NMF / 2 ? NLW : 0) && i - (NLW < NMF / 2 ? NLW : 0) < NLW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if constexpr (ST) read_frag(f0, nxt, 0);
+    mfma_frag(f1);
+    if constexpr (ST) {
+#pragma unroll
+      for (int i = 0; i < NMF; i++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+        if (i < NFR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+      }
+    }
+  };
+  {
+    using T = std::true_type;
+    using F = std::false_type;
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) stage(kt, T{}, T{});
+    if (kt + 1 < nk) {
+      stage(kt, T{}, F{});
+      ++kt;
+    }
+    stage(kt, F{}, F{});
+  }
+
+  // ---- epilogue.  Accumulator layout: D[row = (e&3) + 8*(e>>2) + 4*lhalf][col = lrow]: a store instruction writes two
+  // 128-byte row segments.  bias -> activation -> residual, as gemm.hip.
+  auto run = [&](auto act_c, auto res_c) {
+    constexpr int ACT = decltype(act_c)::value;
+    constexpr bool HASR = decltype(res_c)::value != 0;
+#pragma unroll
+    for (int j = 0; j < WN; j++) {
+      const int n = n0 + wn + j * 32 + lrow;
+      const bool colok = n < g.N;
+      const float bv = (g.bias && colok) ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < WM; i++) {
+        float rv[16];
+        if constexpr (HASR) {
+#pragma unroll
+          for (int e = 0; e < 16; e++) {
+            const int m = min(m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf, g.M - 1);
+            rv[e] = g.R[(size_t)m * g.ldr + (colok ? n : 0)];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const int m = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
+          float v = apply_act_c<ACT>(acc[i][j][e] + bv);
+          if constexpr (HASR) v += rv[e];
+          const size_t crow = g.c_seg ? (size_t)(m / g.c_seg) * g.c_seg_stride + (m % g.c_seg) : (size_t)m;
+          if (colok && m < g.M) g.C[crow * g.ldc + n] = v;
+        }
+      }
+    }
+  };
+  auto run_act = [&](auto act_c) {
+    if (g.R) run(act_c, IntC<1>{});
+    else run(act_c, IntC<0>{});
+  };
+  switch (g.act) {
+    case ACT_GELU: run_act(IntC<ACT_GELU>{}); break;
+    case ACT_SILU: run_act(IntC<ACT_SILU>{}); break;
+    case ACT_TANH: run_act(IntC<ACT_TANH>{}); break;
+    case ACT_LRELU: run_act(IntC<ACT_LRELU>{}); break;
+    default: run_act(IntC<ACT_NONE>{}); break;
+  }
+}
+
+// x = x1 + x2 + x3: planes [3][rows][cols] (bf16 bit patterns).  cols % 8 == 0, 16-byte aligned rows.
+extern "C" int sgic_split3_f32(const float *d_x, int ld, int rows, int cols, int seg, int seg_stride, uint16_t *d_planes,
+                               sgic_stream_t stream) {
+  SGIC_REQUIRE(d_x && d_planes && rows > 0 && cols > 0, "null/empty");
+  SGIC_REQUIRE((cols & 7) == 0 && (ld & 3) == 0 && ld >= cols, "cols % 8, ld % 4");
+  SGIC_REQUIRE(((uintptr_t)d_x & 15) == 0 && ((uintptr_t)d_planes & 15) == 0, "16-byte alignment");
+  SGIC_REQUIRE(seg >= 0 && (seg == 0 || seg_stride >= seg), "row segment map");
+  const long total = (long)rows * (cols >> 3);
+  const unsigned grid = (unsigned)min((total + 255) / 256, 256L * 16);
+  split3_rows_kernel<<<grid, 256, 0, to_stream(stream)>>>(d_x, ld, rows, cols, seg, seg_stride, d_planes);
+  return sgic::check_launch("split3_rows_kernel");
+}
+
+#define SGIC_SPLIT3_TILE_MODES 3
+
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+static int s3_launch(const S3Args &g, hipStream_t st, const sgic_launch_opts *o) {
+  constexpr int NT = 64 * WAVES_M * WAVES_N, TM = 32 * WM * WAVES_M, TN = 32 * WN * WAVES_N;
+  constexpr int LDS = 2 * 3 * (TM + TN) * 64;
+  static bool attr_set = false;   // idempotent: a race sets the same value twice
+  auto kernel = gemm_split3_kernel<WAVES_M, WAVES_N, WM, WN>;
+  if (!attr_set) {
+    SGIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)(((g.M + TM - 1) / TM) * ((g.N + TN - 1) / TN)));
+  if (const auto *evp = prof_next(o)) {
+    hipExtLaunchKernelGGL(kernel, grid, dim3(NT), LDS, st, evp->first, evp->second, 0, g);
+  } else {
+    kernel<<<grid, NT, LDS, st>>>(g);
+  }
+  return sgic::check_launch("gemm_split3_kernel");
+}
+
+// C[M,N] = act(A . W^T + bias) + R with both operands as bf16x3 planes (see the header of this file).
+//   d_A != NULL: A (fp32, lda, row map a_seg) is split into d_Aplanes (caller's workspace, 3*M*K bf16) first;
+//   d_A == NULL: d_Aplanes already holds the planes (written by sgic_split3_f32 or a producing kernel).
+// K % 32 == 0.  opts->tile_mode: 0 = heuristic, 1 = 128x256, 2 = 128x128, 3 = 64x64 tiles (bitwise identical results).
+extern "C" int sgic_gemm_split3_f32(const float *d_A, int lda, int a_seg, int a_seg_stride, uint16_t *d_Aplanes,
+                                    const uint16_t *d_Wplanes, const float *d_bias, const float *d_R, int ldr, float *d_C,
+                                    int ldc, int M, int N, int K, int act, int c_seg, int c_seg_stride,
+                                    const sgic_launch_opts *opts, sgic_stream_t stream) {
+  SGIC_REQUIRE(d_Aplanes && d_Wplanes && d_C && M > 0 && N > 0 && K > 0, "null/empty");
+  SGIC_REQUIRE((K & 31) == 0, "K must be a multiple of 32");
+  SGIC_REQUIRE(((uintptr_t)d_Aplanes & 15) == 0 && ((uintptr_t)d_Wplanes & 15) == 0, "planes must be 16-byte aligned");
+  SGIC_REQUIRE(ldc >= N && (!d_R || ldr >= N), "leading dimensions");
+  SGIC_REQUIRE(act >= 0 && act <= ACT_LRELU, "activation");
+  SGIC_REQUIRE(c_seg >= 0 && (c_seg == 0 || c_seg_stride >= c_seg), "row segment map");
+  if (d_A) {
+    int rc = sgic_split3_f32(d_A, lda, M, K, a_seg, a_seg_stride, d_Aplanes, stream);
+    if (rc) return rc;
+  }
+  S3Args g{d_Aplanes, d_Wplanes, d_bias, d_R, d_C, M, N, K, ldr, ldc, act, c_seg, c_seg_stride, (long)M * K, (long)N * K};
+  int mode = opts ? opts->tile_mode : 0;
+  SGIC_REQUIRE(mode >= 0 && mode <= SGIC_SPLIT3_TILE_MODES, "tile_mode");
+  if (!mode) {
+    // the largest tile whose grid still fills the 256 CUs ~twice over; launches that cannot fill the chip take 64x64
+    const long t256 = (long)((M + 127) / 128) * ((N + 255) / 256), t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    mode = t256 >= 512 ? 1 : (t128 >= 384 ? 2 : 3);
+  }
+  hipStream_t st = to_stream(stream);
+  switch (mode) {
+    case 1: return s3_launch<2, 4, 2, 2>(g, st, opts);
+    case 2: return s3_launch<2, 4, 2, 1>(g, st, opts);
+    default: return s3_launch<2, 2, 1, 1>(g, st, opts);
+  }
+}

@@ -195,20 +195,21 @@ def _tune_profiler():
     return _TUNE_PROF
 
 
-def _tune(key, launch):
+def _tune(key, launch, modes=None):
     """two interleaved passes over the modes, best-of per mode: a single short sample mis-ranks modes that are within
     a few percent of each other (clock ramp, cold L2 after the previous mode's different tile walk).
     Short launches are timed by the DISPATCH's own timestamps (sgic_profiler: hipExtLaunchKernel start / stop events), i.e.
     the kernel's duration alone: host-side event pairs around Python-issued launches cannot rank kernels shorter than the
     ~13 us a launch costs on the host, which is every GEMM of a single-image request."""
     prof = _tune_profiler()
+    modes = TUNE_MODES if modes is None else modes
     reps = 3
     times = {}
     for _ in range(2):
         if M_big(key):
             # launches of >= ~50 us: host-side event pairs around four back-to-back launches, which also charge a mode for
             # what it costs BETWEEN kernels (the ramp of 512 persistent workgroups, the drain); measured better in the model
-            for mode in TUNE_MODES:
+            for mode in modes:
                 launch(mode)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -219,17 +220,17 @@ def _tune(key, launch):
                 t = e0.elapsed_time(e1)
                 times[mode] = min(t, times.get(mode, t))
             continue
-        check(lib.sgic_profiler_begin(prof, len(TUNE_MODES) * reps), "sgic_profiler_begin")
-        for mode in TUNE_MODES:
+        check(lib.sgic_profiler_begin(prof, len(modes) * reps), "sgic_profiler_begin")
+        for mode in modes:
             launch(mode)                               # warm, untimed
             for _ in range(reps):
                 launch(mode, prof)
-        buf = (ctypes.c_float * (len(TUNE_MODES) * reps))()
+        buf = (ctypes.c_float * (len(modes) * reps))()
         n = ctypes.c_int(0)
-        check(lib.sgic_profiler_end(prof, buf, len(TUNE_MODES) * reps, ctypes.byref(n)), "sgic_profiler_end")
-        if n.value != len(TUNE_MODES) * reps:
-            raise RuntimeError(f"tile tuner: {n.value} timed launches, expected {len(TUNE_MODES) * reps}")
-        for i, mode in enumerate(TUNE_MODES):
+        check(lib.sgic_profiler_end(prof, buf, len(modes) * reps, ctypes.byref(n)), "sgic_profiler_end")
+        if n.value != len(modes) * reps:
+            raise RuntimeError(f"tile tuner: {n.value} timed launches, expected {len(modes) * reps}")
+        for i, mode in enumerate(modes):
             t = min(buf[i * reps + r] for r in range(reps))
             times[mode] = min(t, times.get(mode, t))
     order = sorted(times, key=times.get)
@@ -279,7 +280,7 @@ def finalize_autotune():
             _remember(key, min(done, key=lambda m: min(c["t"][m])))
 
 
-def _pick_and_launch(key, launch, big_enough, restore=None):
+def _pick_and_launch(key, launch, big_enough, restore=None, modes=None):
     """shared tile-mode policy of gemm() / conv3x3(): cache -> family neighbour -> race (outside profile windows) -> heuristic.
     Returns True when the launch was already done by an in-context sample."""
     tile = 0
@@ -291,10 +292,10 @@ def _pick_and_launch(key, launch, big_enough, restore=None):
             elif restore is not None:
                 # in-place residual GEMMs (out is residual) are not idempotent: save / restore the buffer around tuning
                 saved = restore.clone()
-                tile = _tune(key, launch)
+                tile = _tune(key, launch, modes)
                 restore.copy_(saved)
             else:
-                tile = _tune(key, launch)
+                tile = _tune(key, launch, modes)
         elif key in _CTX and PROFILE is None:
             _ctx_launch(key, launch)
             return True
@@ -302,10 +303,72 @@ def _pick_and_launch(key, launch, big_enough, restore=None):
     return False
 
 
-def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(0, 0), c_seg=(0, 0), tile=None):
+# ---- GEMM arithmetic: "f32" = the exact-fp32 MFMA (csrc/gemm.hip), "split3" = fp32-accurate bf16x3 split on the bf16 matrix
+# pipe (csrc/gemm_split.hip).  A process-level choice (SGIC_GEMM or set_precision): which kernel family a GEMM takes may
+# depend on (N, K) and on the operands' kinds, never on M, so single-image and batched requests stay bitwise identical.
+PRECISION = os.environ.get("SGIC_GEMM", "f32")
+SPLIT3_MODES = (1, 2, 3)
+_W3 = {}          # (data_ptr, N, K, ldw, version) -> (planes, w): the weight is pinned so its address cannot be reused
+_W3_BYTES = 0
+_W3_LIMIT = 24 << 30
+_A3_WS = {}       # (device, stream) -> workspace for the activation planes
+
+
+def set_precision(p):
+    global PRECISION
+    assert p in ("f32", "split3"), p
+    PRECISION = p
+
+
+def split3(x, ld=None, rows=None, seg=(0, 0), out=None):
+    """x[rows, cols] fp32 -> planes [3, rows, cols] (uint16 = bf16 bit patterns), x = p0 + p1 + p2 exactly"""
+    x, ldx = _rows(x)
+    rows = x.shape[0] if rows is None else rows
+    cols = x.shape[1]
+    if out is None:
+        out = torch.empty(3, rows, cols, device=x.device, dtype=torch.int16)
+    call("sgic_split3_f32", _p(x), ldx if ld is None else ld, rows, cols, seg[0], seg[1], _p(out))
+    return out
+
+
+def weight_planes(w, ldw):
+    """bf16x3 planes of a constant operand, split once (keyed by address + in-place version)"""
+    global _W3_BYTES
+    N, K = w.shape
+    key = (w.data_ptr(), N, K, ldw, w._version)
+    hit = _W3.get(key)
+    if hit is None:
+        planes = torch.empty(3, N, K, device=w.device, dtype=torch.int16)
+        call("sgic_split3_f32", _p(w), ldw, N, K, 0, 0, _p(planes))
+        nbytes = planes.numel() * 2
+        while _W3 and _W3_BYTES + nbytes > _W3_LIMIT:      # oldest first
+            old = next(iter(_W3))
+            _W3_BYTES -= _W3.pop(old)[0].numel() * 2
+        _W3[key] = hit = (planes, w)
+        _W3_BYTES += nbytes
+    return hit[0]
+
+
+def _a3_workspace(dev, n_u16):
+    key = (dev, _stream_key())
+    ws = _A3_WS.get(key)
+    if ws is None or ws.numel() < n_u16:
+        ws = torch.empty(max(n_u16, 1 << 24), device=dev, dtype=torch.int16)
+        _A3_WS[key] = ws
+    return ws
+
+
+def _stream_key():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(0, 0), c_seg=(0, 0), tile=None, w_const=True,
+         precision=None):
     """out[M,N] = act(a[M,K] @ w[N,K]^T + bias) + residual.  a_seg/c_seg = (seg, seg_stride) row maps:
     logical row m of A (resp. C) lives at physical row (m // seg) * seg_stride + m % seg.
-    tile: force a launch mode (tests / tools); default = cache / autotuner."""
+    tile: force a launch mode (tests / tools); default = cache / autotuner.
+    w_const: w is a constant (a model weight): under PRECISION == "split3" its bf16x3 planes are cached.  A `w` whose contents
+    change between calls (the search index) must pass False and takes the fp32 MFMA kernel."""
     require_gpu()
     a, lda = _rows(a)
     w, ldw = _rows(w)
@@ -325,6 +388,25 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(
         assert residual.shape[1] == N and residual.shape[0] >= M
     if bias is not None:
         assert bias.shape == (N,) and bias.is_contiguous()
+    inplace = residual is not None and out.data_ptr() == residual.data_ptr()
+
+    if (precision or PRECISION) == "split3" and w_const and K % 32 == 0:
+        wp = weight_planes(w, ldw)
+        ws = _a3_workspace(a.device, 3 * M * K)
+
+        def launch3(mode, prof=None):
+            call("sgic_gemm_split3_f32", _p(a), lda, a_seg[0], a_seg[1], _p(ws), _p(wp), _p(bias), _p(residual), ldr, _p(out), ldc,
+                 M, N, K, act, c_seg[0], c_seg[1], _opts(tile=mode, prof=prof))
+
+        if tile is not None:
+            launch3(tile)
+        else:
+            key = ("gemm3", M, N, K, int(residual is not None), act)
+            if _pick_and_launch(key, launch3, M * N >= (1 << 16), restore=out if inplace else None, modes=SPLIT3_MODES):
+                return out
+        if PROFILE is not None:
+            PROFILE.append((2.0 * M * N * K, (M, N, K, residual is not None, act)))
+        return out
 
     def launch(mode, prof=None):
         call("sgic_gemm_f32", _p(a), lda, _p(w), ldw, _p(bias), _p(residual), ldr, _p(out), ldc, M, N, K, act,
@@ -334,7 +416,6 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(
         launch(tile)
     else:
         key = ("gemm", M, N, K, int(residual is not None), act)
-        inplace = residual is not None and out.data_ptr() == residual.data_ptr()
         if _pick_and_launch(key, launch, M * N >= (1 << 16), restore=out if inplace else None):
             return out
     if PROFILE is not None:   # the launch took the next event pair of the open profile window (profile_begin)

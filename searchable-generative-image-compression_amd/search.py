@@ -105,7 +105,7 @@ def search_gpu(q, vecs, topk, device="cuda:0"):
     k = max(1, min(topk, vecs.shape[0]))
     dq = torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32)).to(dev)
     db = torch.from_numpy(np.ascontiguousarray(vecs, dtype=np.float32)).to(dev)
-    scores = ops.gemm(dq, db)
+    scores = ops.gemm(dq, db, w_const=False)
     s, i = ops.topk_rows(scores, k)
     return s.cpu().numpy(), i.cpu().numpy()
 

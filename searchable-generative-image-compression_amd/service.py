@@ -228,7 +228,7 @@ class ResidentService:
         k = max(1, min(int(topk), db.shape[0]))
         with self._lock:
             dq = torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32)).to(self.device)
-            s, i = ops.topk_rows(ops.gemm(dq, db), k)                   # exact inner product + top-k (IndexFlatIP.search)
+            s, i = ops.topk_rows(ops.gemm(dq, db, w_const=False), k)                   # exact inner product + top-k (IndexFlatIP.search)
             s, i = s.cpu().numpy(), i.cpu().numpy()
         return [{"path": ids[j], "score": float(s[0, r])} for r, j in enumerate(i[0]) if j != -1]
 

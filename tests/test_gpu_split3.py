@@ -1,0 +1,123 @@
+"""GPU tests of the bf16x3 split GEMM (csrc/gemm_split.hip, through the C ABI): an fp32 GEMM in accuracy, computed on the
+bf16 matrix pipe.
+  * the split is exact: p0 + p1 + p2 == x for every fp32 x (checked in fp64);
+  * error against an fp64 reference is bounded by the error of the plain fp32 path (sgic_gemm_f32: a k-ordered fmaf chain)
+    on the same inputs -- the tolerance that makes this "fp32" rather than "reduced precision";
+  * results are bitwise independent of the tile mode and of M (batch invariance), like the fp32 kernel;
+  * epilogue variants (bias / activation / residual / in-place residual / row maps / ragged M, N) against torch fp64."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import sgic_amd  # noqa
+    from sgic_amd import ops as O
+    return O
+
+
+def _bf16_bits_to_f64(t):
+    return (t.to(torch.int32) << 16).view(torch.float32).double()
+
+
+def test_split_is_exact(ops):
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(257, 1024, device="cuda", generator=g) * torch.exp(4 * torch.randn(257, 1, device="cuda", generator=g))
+    x[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e-39, 65504.0, 1e30, -1e-30], device="cuda")   # incl. an fp32 subnormal
+    p = ops.split3(x)
+    torch.cuda.synchronize()
+    s = _bf16_bits_to_f64(p[0]) + _bf16_bits_to_f64(p[1]) + _bf16_bits_to_f64(p[2])
+    d = (s - x.double()).abs()
+    big = x.abs() > 1e-30            # below that the low pieces are bf16 subnormals (may flush): far under any fp32 ulp that matters
+    assert float(d[big].max()) == 0.0
+    assert float(d[~big].max()) <= 1e-30
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 4096), (512, 1024, 1024), (289, 768, 768)])
+def test_error_not_above_fp32_path(ops, M, N, K):
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) * 0.03
+    ref = a.double() @ w.double().T
+    c3 = ops.gemm(a, w, precision="split3")
+    c1 = ops.gemm(a, w, precision="f32")
+    torch.cuda.synchronize()
+    e3 = float((c3.double() - ref).pow(2).mean().sqrt())
+    e1 = float((c1.double() - ref).pow(2).mean().sqrt())
+    scale = float(ref.pow(2).mean().sqrt())
+    print(f"\n({M},{N},{K}): rms error / rms(C): split3 {e3 / scale:.3e}   fp32 MFMA chain {e1 / scale:.3e}")
+    assert e3 <= 1.10 * e1 + 1e-9 * scale          # measured 0.85-0.9x
+    assert float((c3.double() - ref).abs().max()) <= 1.5 * float((c1.double() - ref).abs().max())
+
+
+def test_bitwise_independent_of_tile_and_batch(ops):
+    g = torch.Generator(device="cuda").manual_seed(11)
+    M, N, K = 1100, 768, 1024
+    a = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) * 0.05
+    bias = torch.randn(N, device="cuda", generator=g)
+    outs = [ops.gemm(a, w, bias, act=ops.ACT_GELU, precision="split3", tile=t) for t in (1, 2, 3)]
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    # a single "image" (rows 289..578) computed alone == the same rows inside the batch
+    one = ops.gemm(a[289:578].contiguous(), w, bias, act=ops.ACT_GELU, precision="split3")
+    torch.cuda.synchronize()
+    assert torch.equal(one, outs[0][289:578])
+
+
+@pytest.mark.parametrize("act", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("res", [False, True])
+def test_epilogues_vs_torch(ops, act, res):
+    g = torch.Generator(device="cuda").manual_seed(act * 2 + res)
+    M, N, K = 333, 200, 96          # ragged M and N (N % 32 != 0), three K slices
+    a = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) * 0.2
+    bias = torch.randn(N, device="cuda", generator=g)
+    r = torch.randn(M, N, device="cuda", generator=g) if res else None
+    for tile in (1, 2, 3):
+        out = ops.gemm(a, w, bias, residual=r, act=act, precision="split3", tile=tile)
+        torch.cuda.synchronize()
+        z = a.double() @ w.double().T + bias.double()
+        z = {0: lambda v: v, 1: lambda v: torch.nn.functional.gelu(v), 2: lambda v: torch.nn.functional.silu(v), 3: torch.tanh,
+             4: lambda v: torch.nn.functional.leaky_relu(v, 0.01)}[act](z)
+        if res:
+            z = z + r.double()
+        assert float((out.double() - z).abs().max()) < 2e-5 * max(1.0, float(z.abs().max()))
+
+
+def test_inplace_residual_and_row_maps(ops):
+    g = torch.Generator(device="cuda").manual_seed(5)
+    n, L, Lt, D = 6, 40, 24, 128
+    w = torch.randn(D, D, device="cuda", generator=g) * 0.1
+    X = torch.randn(n * L, D, device="cuda", generator=g)
+    X0 = X.clone()
+    t = torch.randn(n * L, D, device="cuda", generator=g)
+    ops.gemm(t, w, residual=X, out=X, precision="split3")                       # in place: X += t W^T
+    torch.cuda.synchronize()
+    assert float((X.double() - (X0.double() + t.double() @ w.double().T)).abs().max()) < 1e-4
+    # A rows read from / C rows written to the [:, :Lt] token slice of an (n, L, D) buffer
+    J = torch.randn(n * L, D, device="cuda", generator=g)
+    y = ops.gemm(J, w, M=n * Lt, a_seg=(Lt, L), precision="split3")
+    sl = J.reshape(n, L, D)[:, :Lt].reshape(n * Lt, D)
+    torch.cuda.synchronize()
+    assert float((y.double() - sl.double() @ w.double().T).abs().max()) < 1e-4
+    out = torch.zeros(n * L, D, device="cuda")
+    ops.gemm(sl.contiguous(), w, out=out, M=n * Lt, c_seg=(Lt, L), precision="split3")
+    torch.cuda.synchronize()
+    o3 = out.reshape(n, L, D)
+    assert float((o3[:, :Lt].reshape(n * Lt, D).double() - sl.double() @ w.double().T).abs().max()) < 1e-4
+    assert float(o3[:, Lt:].abs().max()) == 0.0
+
+
+def test_weight_cache_follows_inplace_updates(ops):
+    g = torch.Generator(device="cuda").manual_seed(9)
+    a = torch.randn(64, 64, device="cuda", generator=g)
+    w = torch.randn(64, 64, device="cuda", generator=g)
+    y1 = ops.gemm(a, w, precision="split3")
+    w.mul_(2.0)                                             # bumps the tensor version: the cached planes are not reused
+    y2 = ops.gemm(a, w, precision="split3")
+    torch.cuda.synchronize()
+    assert torch.allclose(y2, 2.0 * y1, rtol=1e-6, atol=1e-6)
