@@ -215,13 +215,19 @@ int sgic_l2norm_u8(const float *d_x, int ldx, int M, int D, float *d_unit, uint8
  *   cols % 8 == 0.  Weights are split once at load time.
  * sgic_gemm_split3_f32: d_A != NULL: A is split into the caller's workspace d_Aplanes (3*M*K uint16) first;
  *   d_A == NULL: d_Aplanes already holds the planes.  K % 32 == 0.
+ *   d_Cplanes != NULL: the result is written as planes [3][M][N] (the next GEMM's A operand) instead of d_C.
  *   opts->tile_mode: 0 = heuristic, 1 = 128x256, 2 = 128x128, 3 = 64x64 workgroup tiles. */
 int sgic_split3_f32(const float *d_x, int ld, int rows, int cols, int seg, int seg_stride, uint16_t *d_planes,
                     sgic_stream_t stream);
 int sgic_gemm_split3_f32(const float *d_A, int lda, int a_seg, int a_seg_stride, uint16_t *d_Aplanes,
                          const uint16_t *d_Wplanes, const float *d_bias, const float *d_R, int ldr, float *d_C, int ldc,
-                         int M, int N, int K, int act, int c_seg, int c_seg_stride, const sgic_launch_opts *opts,
-                         sgic_stream_t stream);
+                         uint16_t *d_Cplanes, int M, int N, int K, int act, int c_seg, int c_seg_stride,
+                         const sgic_launch_opts *opts, sgic_stream_t stream);
+/* nn.LayerNorm (call sites as sgic_layernorm_f32) whose only consumer is a split GEMM: the normalised rows are written
+ * directly as bf16x3 planes [3][M][C] (dense rows), so no fp32 copy and no separate split pass.  C % 256 == 0, C <= 2048. */
+int sgic_layernorm_split3_f32(const float *d_x, int ldx, int xseg, int xseg_stride, const float *d_gamma,
+                              const float *d_beta, uint16_t *d_planes, int M, int C, float eps, int act,
+                              sgic_stream_t stream);
 
 /* Batched GEMM (element strides, 0 = shared operand) -- VQGAN AttnBlock single-head attention as
  * S_b = Q_b K_b^T, O_b = P_b V_b (taming/modules/diffusionmodules/model.py:168-192). */

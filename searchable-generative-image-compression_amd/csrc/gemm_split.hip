@@ -28,25 +28,12 @@
 #include "common.h"
 #include "gemm_act.h"
 #include "profiler.h"
+#include "split3.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ unsigned s3_pk_bf16(float lo, float hi) {   // v_cvt_pk_bf16_f32: round to nearest even
-  bf16x2 r = {(__bf16)lo, (__bf16)hi};
-  return __builtin_bit_cast(unsigned, r);
-}
-// (x0, x1) -> the three bf16 pairs; the residuals are exact in fp32 (each step removes the leading 8 bits)
-__device__ __forceinline__ void s3_split_pair(float x0, float x1, unsigned &p1, unsigned &p2, unsigned &p3) {
-  p1 = s3_pk_bf16(x0, x1);
-  const float r0 = x0 - __uint_as_float(p1 << 16), r1 = x1 - __uint_as_float(p1 & 0xffff0000u);
-  p2 = s3_pk_bf16(r0, r1);
-  const float s0 = r0 - __uint_as_float(p2 << 16), s1 = r1 - __uint_as_float(p2 & 0xffff0000u);
-  p3 = s3_pk_bf16(s0, s1);
-}
 
 // x[rows, cols] fp32 (row map as sgic_gemm_f32's A operand) -> planes [3][rows][cols] bf16; 8 elements per thread
 __global__ __launch_bounds__(256) void split3_rows_kernel(const float *__restrict__ x, int ld, int rows, int cols, int seg,
@@ -76,6 +63,8 @@ struct S3Args {
   int M, N, K, ldr, ldc, act;
   int c_seg, c_seg_stride;
   long a_plane, w_plane;         // elements between planes
+  unsigned short *Cp;            // optional: the result as bf16x3 planes [3][M][N] (the next GEMM's A operand) instead of C
+  int vec_epilogue;              // C / R / bias rows are float4-addressable
 };
 
 template <int WAVES_M, int WAVES_N, int WM, int WN>
@@ -214,8 +203,83 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void gemm_split3_kernel(
     stage(kt, F{}, F{});
   }
 
-  // ---- epilogue.  Accumulator layout: D[row = (e&3) + 8*(e>>2) + 4*lhalf][col = lrow]: a store instruction writes two
-  // 128-byte row segments.  bias -> activation -> residual, as gemm.hip.
+  // ---- epilogue.  Accumulator layout: D[row = (e&3) + 8*(e>>2) + 4*lhalf][col = lrow].  bias -> activation -> residual,
+  // as gemm.hip.  Wide path: each wave transposes 32 rows at a time through its own LDS slice (nobody reads the staging
+  // buffers after the last barrier) and writes whole row segments, as float4 or -- when the consumer is the next GEMM --
+  // directly as bf16x3 planes (8 bytes per lane and plane).
+  if (g.vec_epilogue) {
+    constexpr int TW = 32 * WN, LPR = TW / 4, RPI = 64 / LPR, NIT = 32 / RPI;
+    float *ep = reinterpret_cast<float *>(smem) + wave * (32 * TW);
+    const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
+    const int n = n0 + wn + c4;
+    const bool colok = n < g.N;
+    const int nc = colok ? n : 0;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias && colok) bv = *reinterpret_cast<const f32x4 *>(g.bias + n);
+    auto run = [&](auto act_c, auto res_c, auto pl_c) {
+      constexpr int ACT = decltype(act_c)::value;
+      constexpr bool HASR = decltype(res_c)::value != 0, PLANES = decltype(pl_c)::value != 0;
+#pragma unroll
+      for (int i = 0; i < WM; i++) {
+        f32x4 rv[NIT];
+        if constexpr (HASR) {
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const int m = min(m0 + wm + i * 32 + it * RPI + r0, g.M - 1);
+            rv[it] = *reinterpret_cast<const f32x4 *>(g.R + (size_t)m * g.ldr + nc);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < WN; j++)
+#pragma unroll
+          for (int e = 0; e < 16; e++) ep[((e & 3) + 8 * (e >> 2) + 4 * lhalf) * TW + j * 32 + lrow] = acc[i][j][e];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        constexpr int EB = NIT < 4 ? NIT : 4;
+#pragma unroll
+        for (int b = 0; b < NIT; b += EB) {
+          f32x4 cv[EB];
+#pragma unroll
+          for (int q = 0; q < EB; ++q) cv[q] = *reinterpret_cast<const f32x4 *>(ep + ((b + q) * RPI + r0) * TW + c4);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int q = 0; q < EB; ++q) {
+            const int it = b + q;
+            const int m = m0 + wm + i * 32 + it * RPI + r0;
+            f32x4 v = cv[q];
+#pragma unroll
+            for (int t = 0; t < 4; t++) v[t] = apply_act_c<ACT>(v[t] + bv[t]);
+            if constexpr (HASR) v += rv[it];
+            if (colok && m < g.M) {
+              if constexpr (PLANES) {
+                s3_store4(g.Cp, (long)g.M * g.N, (size_t)m * g.N + n, v);
+              } else {
+                const size_t crow = g.c_seg ? (size_t)(m / g.c_seg) * g.c_seg_stride + (m % g.c_seg) : (size_t)m;
+                *reinterpret_cast<f32x4 *>(g.C + crow * g.ldc + n) = v;
+              }
+            }
+          }
+        }
+      }
+    };
+    auto run_act = [&](auto act_c) {
+      if (g.Cp) {
+        if (g.R) run(act_c, IntC<1>{}, IntC<1>{});
+        else run(act_c, IntC<0>{}, IntC<1>{});
+      } else {
+        if (g.R) run(act_c, IntC<1>{}, IntC<0>{});
+        else run(act_c, IntC<0>{}, IntC<0>{});
+      }
+    };
+    switch (g.act) {
+      case ACT_GELU: run_act(IntC<ACT_GELU>{}); break;
+      case ACT_SILU: run_act(IntC<ACT_SILU>{}); break;
+      case ACT_TANH: run_act(IntC<ACT_TANH>{}); break;
+      case ACT_LRELU: run_act(IntC<ACT_LRELU>{}); break;
+      default: run_act(IntC<ACT_NONE>{}); break;
+    }
+    return;
+  }
+  // narrow path (N or the leading dimensions not float4-addressable): one dword per lane
   auto run = [&](auto act_c, auto res_c) {
     constexpr int ACT = decltype(act_c)::value;
     constexpr bool HASR = decltype(res_c)::value != 0;
@@ -226,21 +290,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void gemm_split3_kernel(
       const float bv = (g.bias && colok) ? g.bias[n] : 0.f;
 #pragma unroll
       for (int i = 0; i < WM; i++) {
-        float rv[16];
-        if constexpr (HASR) {
-#pragma unroll
-          for (int e = 0; e < 16; e++) {
-            const int m = min(m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf, g.M - 1);
-            rv[e] = g.R[(size_t)m * g.ldr + (colok ? n : 0)];
-          }
-        }
 #pragma unroll
         for (int e = 0; e < 16; e++) {
           const int m = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
-          float v = apply_act_c<ACT>(acc[i][j][e] + bv);
-          if constexpr (HASR) v += rv[e];
-          const size_t crow = g.c_seg ? (size_t)(m / g.c_seg) * g.c_seg_stride + (m % g.c_seg) : (size_t)m;
-          if (colok && m < g.M) g.C[crow * g.ldc + n] = v;
+          if (colok && m < g.M) {
+            float v = apply_act_c<ACT>(acc[i][j][e] + bv);
+            if constexpr (HASR) v += g.R[(size_t)m * g.ldr + n];
+            const size_t crow = g.c_seg ? (size_t)(m / g.c_seg) * g.c_seg_stride + (m % g.c_seg) : (size_t)m;
+            g.C[crow * g.ldc + n] = v;
+          }
         }
       }
     }
@@ -295,22 +353,26 @@ static int s3_launch(const S3Args &g, hipStream_t st, const sgic_launch_opts *o)
 // C[M,N] = act(A . W^T + bias) + R with both operands as bf16x3 planes (see the header of this file).
 //   d_A != NULL: A (fp32, lda, row map a_seg) is split into d_Aplanes (caller's workspace, 3*M*K bf16) first;
 //   d_A == NULL: d_Aplanes already holds the planes (written by sgic_split3_f32 or a producing kernel).
+//   d_Cplanes != NULL: the result is written as planes [3][M][N] (the A operand of the next GEMM) instead of d_C.
 // K % 32 == 0.  opts->tile_mode: 0 = heuristic, 1 = 128x256, 2 = 128x128, 3 = 64x64 tiles (bitwise identical results).
 extern "C" int sgic_gemm_split3_f32(const float *d_A, int lda, int a_seg, int a_seg_stride, uint16_t *d_Aplanes,
                                     const uint16_t *d_Wplanes, const float *d_bias, const float *d_R, int ldr, float *d_C,
-                                    int ldc, int M, int N, int K, int act, int c_seg, int c_seg_stride,
+                                    int ldc, uint16_t *d_Cplanes, int M, int N, int K, int act, int c_seg, int c_seg_stride,
                                     const sgic_launch_opts *opts, sgic_stream_t stream) {
-  SGIC_REQUIRE(d_Aplanes && d_Wplanes && d_C && M > 0 && N > 0 && K > 0, "null/empty");
+  SGIC_REQUIRE(d_Aplanes && d_Wplanes && (d_C || d_Cplanes) && M > 0 && N > 0 && K > 0, "null/empty");
   SGIC_REQUIRE((K & 31) == 0, "K must be a multiple of 32");
   SGIC_REQUIRE(((uintptr_t)d_Aplanes & 15) == 0 && ((uintptr_t)d_Wplanes & 15) == 0, "planes must be 16-byte aligned");
-  SGIC_REQUIRE(ldc >= N && (!d_R || ldr >= N), "leading dimensions");
+  SGIC_REQUIRE((d_Cplanes || ldc >= N) && (!d_R || ldr >= N), "leading dimensions");
   SGIC_REQUIRE(act >= 0 && act <= ACT_LRELU, "activation");
   SGIC_REQUIRE(c_seg >= 0 && (c_seg == 0 || c_seg_stride >= c_seg), "row segment map");
   if (d_A) {
     int rc = sgic_split3_f32(d_A, lda, M, K, a_seg, a_seg_stride, d_Aplanes, stream);
     if (rc) return rc;
   }
-  S3Args g{d_Aplanes, d_Wplanes, d_bias, d_R, d_C, M, N, K, ldr, ldc, act, c_seg, c_seg_stride, (long)M * K, (long)N * K};
+  const int vec = (N % 4 == 0) && (!d_bias || ((uintptr_t)d_bias & 15) == 0) && (!d_R || ((ldr % 4 == 0) && ((uintptr_t)d_R & 15) == 0)) &&
+                  (d_Cplanes ? ((uintptr_t)d_Cplanes & 7) == 0 : ((ldc % 4 == 0) && ((uintptr_t)d_C & 15) == 0));
+  SGIC_REQUIRE(!d_Cplanes || (vec && c_seg == 0), "planes output needs float4-addressable operands and no row map");
+  S3Args g{d_Aplanes, d_Wplanes, d_bias, d_R, d_C, M, N, K, ldr, ldc, act, c_seg, c_seg_stride, (long)M * K, (long)N * K, d_Cplanes, vec};
   int mode = opts ? opts->tile_mode : 0;
   SGIC_REQUIRE(mode >= 0 && mode <= SGIC_SPLIT3_TILE_MODES, "tile_mode");
   if (!mode) {

@@ -6,6 +6,7 @@
 // Rows can be addressed through a segment map  row(m) = (m / seg) * seg_stride + (m % seg)  so a slice
 // [:, a:b] of an (n, L, C) token buffer is normalised in place without a gather.
 #include "common.h"
+#include "split3.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -20,11 +21,13 @@ __device__ __forceinline__ float act_f(float v, int act) {
   return v;
 }
 
+// planes != null: the normalised row goes out as bf16x3 planes [3][M][C] (the A operand of a split GEMM, gemm_split.hip)
+// instead of y
 template <int NV>  // NV float4 per lane: C = NV*256
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, int ldx, int xseg, int xseg_stride,
                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
                                                         float *__restrict__ y, int ldy, int yseg, int yseg_stride, int M,
-                                                        int C, float eps, int act) {
+                                                        int C, float eps, int act, unsigned short *__restrict__ planes) {
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
@@ -58,7 +61,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     f32x4 o;
 #pragma unroll
     for (int t = 0; t < 4; t++) o[t] = act_f((v[i][t] - mean) * rstd * g[t] + b[t], act);
-    *reinterpret_cast<f32x4 *>(yp + c) = o;
+    if (planes) s3_store4(planes, (long)M * C, (size_t)m * C + c, o);
+    else *reinterpret_cast<f32x4 *>(yp + c) = o;
   }
 }
 
@@ -97,18 +101,20 @@ __global__ __launch_bounds__(256) void layernorm_generic_kernel(const float *__r
   }
 }
 
-extern "C" int sgic_layernorm_f32(const float *d_x, int ldx, int xseg, int xseg_stride, const float *d_gamma,
-                                  const float *d_beta, float *d_y, int ldy, int yseg, int yseg_stride, int M, int C,
-                                  float eps, int act, sgic_stream_t stream) {
-  SGIC_REQUIRE(d_x && d_gamma && d_beta && d_y && M > 0 && C > 0, "args");
-  SGIC_REQUIRE((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= C, "C, ldx, ldy multiples of 4");
+static int layernorm_any(const float *d_x, int ldx, int xseg, int xseg_stride, const float *d_gamma, const float *d_beta,
+                         float *d_y, int ldy, int yseg, int yseg_stride, int M, int C, float eps, int act,
+                         unsigned short *d_planes, sgic_stream_t stream) {
+  SGIC_REQUIRE(d_x && d_gamma && d_beta && (d_y || d_planes) && M > 0 && C > 0, "args");
+  SGIC_REQUIRE((C & 3) == 0 && (ldx & 3) == 0 && ldx >= C, "C, ldx multiples of 4");
+  SGIC_REQUIRE(d_planes || ((ldy & 3) == 0 && ldy >= C), "ldy");
+  SGIC_REQUIRE(!d_planes || (C % 256 == 0 && C <= 2048 && ((uintptr_t)d_planes & 7) == 0), "planes output: C % 256 == 0, C <= 2048");
   SGIC_REQUIRE((((uintptr_t)d_x | (uintptr_t)d_y | (uintptr_t)d_gamma | (uintptr_t)d_beta) & 15) == 0, "alignment");
   SGIC_REQUIRE(act == 0 || act == 2, "act: none or SiLU");
   const unsigned grid = cdiv(M, 4);
   hipStream_t st = to_stream(stream);
 #define LN_LAUNCH(NV)                                                                                              \
   layernorm_kernel<NV><<<grid, 256, 0, st>>>(d_x, ldx, xseg, xseg_stride, d_gamma, d_beta, d_y, ldy, yseg, yseg_stride, \
-                                              M, C, eps, act)
+                                              M, C, eps, act, d_planes)
   if (C % 256 == 0 && C <= 2048) {
     switch (C / 256) {
       case 1: LN_LAUNCH(1); break;
@@ -125,4 +131,18 @@ extern "C" int sgic_layernorm_f32(const float *d_x, int ldx, int xseg, int xseg_
                                                    yseg_stride, M, C, eps, act);
   }
   return sgic::check_launch("layernorm_kernel");
+}
+
+extern "C" int sgic_layernorm_f32(const float *d_x, int ldx, int xseg, int xseg_stride, const float *d_gamma,
+                                  const float *d_beta, float *d_y, int ldy, int yseg, int yseg_stride, int M, int C,
+                                  float eps, int act, sgic_stream_t stream) {
+  return layernorm_any(d_x, ldx, xseg, xseg_stride, d_gamma, d_beta, d_y, ldy, yseg, yseg_stride, M, C, eps, act, nullptr, stream);
+}
+
+// LayerNorm whose output is consumed only by a split GEMM: written directly as bf16x3 planes [3][M][C] (dense rows)
+extern "C" int sgic_layernorm_split3_f32(const float *d_x, int ldx, int xseg, int xseg_stride, const float *d_gamma,
+                                         const float *d_beta, uint16_t *d_planes, int M, int C, float eps, int act,
+                                         sgic_stream_t stream) {
+  SGIC_REQUIRE(d_planes, "planes");
+  return layernorm_any(d_x, ldx, xseg, xseg_stride, d_gamma, d_beta, nullptr, 0, 0, 0, M, C, eps, act, d_planes, stream);
 }

@@ -36,13 +36,15 @@ class RabW:
 def rab_forward(X, w: RabW, L, nseq, heads, bias=None):
     """in place on X [(nseq*L), D]; bias: optional (1,L,L) additive attention mask (CLIP text tower: causal)"""
     D = X.shape[1]
-    h = ops.layernorm(X, w.ln1w, w.ln1b)
+    # to_gemm: an activation whose only consumer is the next GEMM goes out as that GEMM's operand (bf16x3 planes under the
+    # split arithmetic, the plain fp32 tensor otherwise)
+    h = ops.layernorm(X, w.ln1w, w.ln1b, to_gemm=True)
     qkv = ops.gemm(h, w.inw, w.inb)
-    att = h  # reuse the LN buffer for the attention output
+    att = h if torch.is_tensor(h) else torch.empty_like(X)   # fp32: reuse the LN buffer for the attention output
     ops.attention(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], att, L, nseq, heads, bias=bias)
     ops.gemm(att, w.ow, w.ob, residual=X, out=X)
-    ops.layernorm(X, w.ln2w, w.ln2b, out=h)
-    f = ops.gemm(h, w.fcw, w.fcb, act=ops.ACT_GELU)
+    h = ops.layernorm(X, w.ln2w, w.ln2b, out=h, to_gemm=True)
+    f = ops.gemm(h, w.fcw, w.fcb, act=ops.ACT_GELU, to_gemm=True)
     ops.gemm(f, w.pjw, w.pjb, residual=X, out=X)
     return X
 
@@ -106,14 +108,15 @@ def swin_forward(Fm, w: SwinW, B, H, W, win=16):
     """in place on the TM16 feature map Fm [(B*H*W), C]"""
     C = Fm.shape[1]
     rowmap, var = swin_rowmap(B, H, W, win, w.shifted, Fm.device)
-    h = ops.layernorm(Fm, w.n1w, w.n1b)
+    h = ops.layernorm(Fm, w.n1w, w.n1b, to_gemm=True)
     qkv = ops.gemm(h, w.qkvw)
     nseq = B * (H // win) * (W // win)
-    ops.attention(qkv[:, 0:C], qkv[:, C:2 * C], qkv[:, 2 * C:3 * C], h, win * win, nseq, C // 64, rowmap=rowmap,
+    att = h if torch.is_tensor(h) else torch.empty_like(Fm)
+    ops.attention(qkv[:, 0:C], qkv[:, C:2 * C], qkv[:, 2 * C:3 * C], att, win * win, nseq, C // 64, rowmap=rowmap,
                   bias=w.bias, biasvar=var if w.shifted else None)
-    ops.gemm(h, w.ow, w.ob, residual=Fm, out=Fm)
-    ops.layernorm(Fm, w.n2w, w.n2b, out=h)
-    f = ops.gemm(h, w.w0, w.b0, act=ops.ACT_GELU)
+    ops.gemm(att, w.ow, w.ob, residual=Fm, out=Fm)
+    h = ops.layernorm(Fm, w.n2w, w.n2b, out=h, to_gemm=True)
+    f = ops.gemm(h, w.w0, w.b0, act=ops.ACT_GELU, to_gemm=True)
     ops.gemm(f, w.w2, w.b2, residual=Fm, out=Fm)
     return Fm
 
@@ -136,8 +139,8 @@ class ConvNextW:
 
 def convnext_forward(Fm, w: ConvNextW, B, H, W):
     t = ops.dwconv(Fm, w.dw, w.db, w.ls, B, H, W, 5, tile16=True)
-    ops.layernorm(t, w.nw, w.nb, out=t)
-    f = ops.gemm(t, w.w0, w.b0, act=ops.ACT_GELU)
+    t = ops.layernorm(t, w.nw, w.nb, out=t, to_gemm=True)
+    f = ops.gemm(t, w.w0, w.b0, act=ops.ACT_GELU, to_gemm=True)
     ops.gemm(f, w.w2, w.b2, residual=Fm, out=Fm)
     return Fm
 
@@ -167,10 +170,10 @@ def cross_forward(Fm, X, w: CrossW, N, Lt, P2):
     ops.add_rows_bcast(Fm, P2, w.fpos, J[Lt:], LJ, N, P2)
     for rw in w.attn:
         rab_forward(J, rw, LJ, N, Fd // 64)
-    t = ops.layernorm(J[Lt:], w.fnw, w.fnb, M=N * P2, x_seg=(P2, LJ))
+    t = ops.layernorm(J[Lt:], w.fnw, w.fnb, M=N * P2, x_seg=(P2, LJ), to_gemm=True)
     ops.gemm(t, w.fw, w.fb, residual=Fm, out=Fm)
     t = ops.gemm(J, w.dw, w.db, M=N * Lt, a_seg=(Lt, LJ))
-    ops.layernorm(t, w.dnw, w.dnb, out=t, act=ops.ACT_SILU)
+    t = ops.layernorm(t, w.dnw, w.dnb, out=t, act=ops.ACT_SILU, to_gemm=True)
     ops.gemm(t, w.zw, w.zb, residual=X, out=X)
     return Fm, X
 

@@ -320,6 +320,39 @@ def set_precision(p):
     PRECISION = p
 
 
+class Planes:
+    """an activation held as bf16x3 planes [3, rows, cols] (int16 bit patterns): the A operand of a split GEMM written
+    directly by its producer (layernorm / gemm epilogue), so no fp32 copy and no separate split pass exists"""
+    __slots__ = ("t", "rows", "cols")
+
+    def __init__(self, rows, cols, device, buf=None):
+        n = 3 * rows * cols
+        if buf is not None and buf.numel() >= n:
+            self.t = buf
+        else:
+            self.t = torch.empty(n, device=device, dtype=torch.int16)
+        self.rows, self.cols = rows, cols
+
+    @property
+    def shape(self):
+        return (self.rows, self.cols)
+
+    @property
+    def device(self):
+        return self.t.device
+
+    def float(self):
+        """the fp32 values (tests / debugging): the sum of the three planes"""
+        p = self.t[:3 * self.rows * self.cols].view(3, self.rows, self.cols)
+        f = lambda q: (q.to(torch.int32) << 16).view(torch.float32)
+        return (f(p[0]) + f(p[1])) + f(p[2])
+
+
+def planes_ok(cols, precision=None):
+    """may a producer hand its [rows, cols] output to the next GEMM as planes?"""
+    return (precision or PRECISION) == "split3" and cols % 32 == 0
+
+
 def split3(x, ld=None, rows=None, seg=(0, 0), out=None):
     """x[rows, cols] fp32 -> planes [3, rows, cols] (uint16 = bf16 bit patterns), x = p0 + p1 + p2 exactly"""
     x, ldx = _rows(x)
@@ -363,50 +396,72 @@ def _stream_key():
 
 
 def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(0, 0), c_seg=(0, 0), tile=None, w_const=True,
-         precision=None):
+         precision=None, to_gemm=False):
     """out[M,N] = act(a[M,K] @ w[N,K]^T + bias) + residual.  a_seg/c_seg = (seg, seg_stride) row maps:
     logical row m of A (resp. C) lives at physical row (m // seg) * seg_stride + m % seg.
     tile: force a launch mode (tests / tools); default = cache / autotuner.
     w_const: w is a constant (a model weight): under PRECISION == "split3" its bf16x3 planes are cached.  A `w` whose contents
-    change between calls (the search index) must pass False and takes the fp32 MFMA kernel."""
+    change between calls (the search index) must pass False and takes the fp32 MFMA kernel.
+    a may be a Planes object (written by a producer called with to_gemm=True).  to_gemm=True: the result feeds only another
+    GEMM as its A operand -> returned as Planes when the split path is active (else the fp32 tensor as always); `out` may
+    then be a Planes object to reuse."""
     require_gpu()
-    a, lda = _rows(a)
+    a_planes = a if isinstance(a, Planes) else None
+    if a_planes is not None:
+        K, lda = a_planes.cols, a_planes.cols
+        assert a_seg[0] == 0 and (M is None or M == a_planes.rows)
+        M = a_planes.rows
+        dev = a_planes.device
+    else:
+        a, lda = _rows(a)
+        K = a.shape[1]
+        if M is None:
+            M = a.shape[0]
+        dev = a.device
     w, ldw = _rows(w)
-    K = a.shape[1]
-    if M is None:
-        M = a.shape[0]
     N = w.shape[0]
-    assert w.shape[1] == K, (a.shape, w.shape)
-    if out is None:
-        assert c_seg[0] == 0
-        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
-    out, ldc = _rows(out)
-    assert out.shape[1] == N
+    assert w.shape[1] == K, ((M, K), w.shape)
+    use3 = (precision or PRECISION) == "split3" and w_const and K % 32 == 0
+    assert a_planes is None or use3, "a Planes operand needs the split path"
+    out_planes = None
+    if to_gemm and use3 and N % 32 == 0 and c_seg[0] == 0:
+        out_planes = out if isinstance(out, Planes) and out.shape == (M, N) else Planes(M, N, dev, buf=out.t if isinstance(out, Planes) else None)
+        out, ldc = None, N
+    else:
+        if isinstance(out, Planes):
+            out = None
+        if out is None:
+            assert c_seg[0] == 0
+            out = torch.empty(M, N, device=dev, dtype=torch.float32)
+        out, ldc = _rows(out)
+        assert out.shape[1] == N
     ldr = 0
     if residual is not None:
         residual, ldr = _rows(residual)
         assert residual.shape[1] == N and residual.shape[0] >= M
     if bias is not None:
         assert bias.shape == (N,) and bias.is_contiguous()
-    inplace = residual is not None and out.data_ptr() == residual.data_ptr()
+    inplace = residual is not None and out is not None and out.data_ptr() == residual.data_ptr()
 
-    if (precision or PRECISION) == "split3" and w_const and K % 32 == 0:
+    if use3:
         wp = weight_planes(w, ldw)
-        ws = _a3_workspace(a.device, 3 * M * K)
+        ap = a_planes.t if a_planes is not None else _a3_workspace(dev, 3 * M * K)
+        a_f32 = None if a_planes is not None else a
+        cp = out_planes.t if out_planes is not None else None
 
         def launch3(mode, prof=None):
-            call("sgic_gemm_split3_f32", _p(a), lda, a_seg[0], a_seg[1], _p(ws), _p(wp), _p(bias), _p(residual), ldr, _p(out), ldc,
-                 M, N, K, act, c_seg[0], c_seg[1], _opts(tile=mode, prof=prof))
+            call("sgic_gemm_split3_f32", _p(a_f32), lda, a_seg[0], a_seg[1], _p(ap), _p(wp), _p(bias), _p(residual), ldr, _p(out), ldc,
+                 _p(cp), M, N, K, act, c_seg[0], c_seg[1], _opts(tile=mode, prof=prof))
 
         if tile is not None:
             launch3(tile)
         else:
             key = ("gemm3", M, N, K, int(residual is not None), act)
             if _pick_and_launch(key, launch3, M * N >= (1 << 16), restore=out if inplace else None, modes=SPLIT3_MODES):
-                return out
+                return out_planes if out_planes is not None else out
         if PROFILE is not None:
             PROFILE.append((2.0 * M * N * K, (M, N, K, residual is not None, act)))
-        return out
+        return out_planes if out_planes is not None else out
 
     def launch(mode, prof=None):
         call("sgic_gemm_f32", _p(a), lda, _p(w), ldw, _p(bias), _p(residual), ldr, _p(out), ldc, M, N, K, act,
@@ -423,16 +478,24 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(
     return out
 
 
-def layernorm(x, gamma, beta, out=None, eps=1e-5, act=ACT_NONE, M=None, x_seg=(0, 0), y_seg=(0, 0)):
+def layernorm(x, gamma, beta, out=None, eps=1e-5, act=ACT_NONE, M=None, x_seg=(0, 0), y_seg=(0, 0), to_gemm=False):
+    """to_gemm=True: the output feeds only a GEMM as its A operand -> written directly as bf16x3 Planes when the split path is
+    active and the width allows it (`out` may be a Planes object to reuse); otherwise the fp32 tensor as always."""
     x, ldx = _rows(x)
     C = x.shape[1]
     if M is None:
         M = x.shape[0]
+    assert gamma.shape == (C,) and beta.shape == (C,)
+    if to_gemm and planes_ok(C) and C % 256 == 0 and C <= 2048 and y_seg[0] == 0:
+        pl = out if isinstance(out, Planes) and out.shape == (M, C) else Planes(M, C, x.device, buf=out.t if isinstance(out, Planes) else None)
+        call("sgic_layernorm_split3_f32", _p(x), ldx, x_seg[0], x_seg[1], _p(gamma), _p(beta), _p(pl.t), M, C, float(eps), act)
+        return pl
+    if isinstance(out, Planes):
+        out = None
     if out is None:
         assert y_seg[0] == 0
         out = torch.empty(M, C, device=x.device, dtype=torch.float32)
     out, ldy = _rows(out)
-    assert gamma.shape == (C,) and beta.shape == (C,)
     call("sgic_layernorm_f32", _p(x), ldx, x_seg[0], x_seg[1], _p(gamma), _p(beta), _p(out), ldy, y_seg[0], y_seg[1],
          M, C, float(eps), act)
     return out

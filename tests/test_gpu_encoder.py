@@ -233,11 +233,11 @@ def test_profile_window_times_every_gemm_launch():
     from sgic_amd import ops
     a = torch.randn(2048, 512, device="cuda:0")
     w = torch.randn(1024, 512, device="cuda:0")
-    ref = ops.gemm(a, w)
-    ops.gemm(a[:64], w[:64])          # warm: the latency assertion below is about the steady state, not a cold code object
+    ref = ops.gemm(a, w, precision="f32")
+    ops.gemm(a[:64], w[:64], precision="f32")          # warm: the latency assertion below is about the steady state, not a cold code object
     ops.profile_begin(16)
-    outs = [ops.gemm(a, w) for _ in range(3)]
-    small = ops.gemm(a[:64], w[:64])
+    outs = [ops.gemm(a, w, precision="f32") for _ in range(3)]
+    small = ops.gemm(a[:64], w[:64], precision="f32")
     recs = ops.profile_end()
     assert ops.PROFILE is None and len(recs) == 4
     assert all(ms > 0.0 for _, ms, _ in recs) and recs[0][0] == 2.0 * 2048 * 1024 * 512 and recs[3][2][:3] == (64, 64, 512)
@@ -271,8 +271,8 @@ def test_gemm_fuzz_all_tile_modes_identical_and_close_to_fp64():
             act = int(rng.integers(0, 5))
             outs = []
             for mode in ops.TUNE_MODES:
-                outs.append(ops.gemm(a, w, b, residual=res, act=act, tile=mode))
-            outs.append(ops.gemm(a, w, b, residual=res, act=act, tile=0))     # built-in heuristic
+                outs.append(ops.gemm(a, w, b, residual=res, act=act, tile=mode, precision="f32"))
+            outs.append(ops.gemm(a, w, b, residual=res, act=act, tile=0, precision="f32"))     # built-in heuristic
             assert all(torch.equal(o, outs[0]) for o in outs[1:]), (M, N, K, act)
             pre = a.double() @ w.double().T + b.double()
             f = {0: lambda v: v, 1: lambda v: torch.nn.functional.gelu(v), 2: lambda v: torch.nn.functional.silu(v), 3: torch.tanh,
@@ -287,7 +287,7 @@ def test_gemm_fuzz_all_tile_modes_identical_and_close_to_fp64():
         w = torch.from_numpy(rng.standard_normal((D, 32), dtype=np.float32)).to(dev)
         for mode in (0, 1, 4, 11, 12, 13, 15):
             buf.zero_()
-            ops.gemm(a, w, out=buf, M=n * Lr, a_seg=(Lr, L), c_seg=(Lr, L), tile=mode)
+            ops.gemm(a, w, out=buf, M=n * Lr, a_seg=(Lr, L), c_seg=(Lr, L), tile=mode, precision="f32")
             ref = (a.view(n, L, 32)[:, :Lr].double() @ w.double().T).float()
             got = buf.view(n, L, D)
             assert float((got[:, :Lr] - ref).abs().max()) < 1e-4 and float(got[:, Lr:].abs().max()) == 0.0, mode

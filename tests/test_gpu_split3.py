@@ -121,3 +121,42 @@ def test_weight_cache_follows_inplace_updates(ops):
     y2 = ops.gemm(a, w, precision="split3")
     torch.cuda.synchronize()
     assert torch.allclose(y2, 2.0 * y1, rtol=1e-6, atol=1e-6)
+
+
+def test_planes_producers_match_the_two_step_path(ops):
+    """layernorm / GEMM epilogues that write bf16x3 planes directly == fp32 output followed by the split pass, bitwise"""
+    g = torch.Generator(device="cuda").manual_seed(21)
+    M, C, N = 700, 1024, 768
+    x = torch.randn(M, C, device="cuda", generator=g) * 3 + 0.5
+    gamma = torch.randn(C, device="cuda", generator=g)
+    beta = torch.randn(C, device="cuda", generator=g)
+    w1 = torch.randn(N, C, device="cuda", generator=g) * 0.05
+    b1 = torch.randn(N, device="cuda", generator=g)
+    w2 = torch.randn(C, N, device="cuda", generator=g) * 0.05
+    old = ops.PRECISION
+    ops.set_precision("split3")
+    try:
+        h_pl = ops.layernorm(x, gamma, beta, to_gemm=True)
+        assert isinstance(h_pl, ops.Planes)
+        h = ops.layernorm(x, gamma, beta)
+        torch.cuda.synchronize()
+        assert torch.equal(h_pl.float(), h)                                 # the planes carry the fp32 value exactly
+        for tile in (1, 2, 3):
+            f_pl = ops.gemm(h_pl, w1, b1, act=ops.ACT_GELU, to_gemm=True, tile=tile)
+            f = ops.gemm(h, w1, b1, act=ops.ACT_GELU, tile=tile)
+            torch.cuda.synchronize()
+            # the same planes as the split pass makes of the fp32 output (tiny GELU tails, < 1e-30, lose their subnormal low pieces
+            # either way, so the comparison is between the planes, not with f itself)
+            assert isinstance(f_pl, ops.Planes) and torch.equal(f_pl.t.view(3, M, N), ops.split3(f))
+            assert float((f_pl.float() - f).abs().max()) < 1e-30
+            y_pl = ops.gemm(f_pl, w2, residual=x, tile=tile)
+            y = ops.gemm(f, w2, residual=x, tile=tile)
+            torch.cuda.synchronize()
+            assert torch.equal(y_pl, y)
+        # SiLU-fused LN and a row-mapped input (cross blocks)
+        t_pl = ops.layernorm(x, gamma, beta, act=ops.ACT_SILU, M=2 * 300, x_seg=(300, 350), to_gemm=True)
+        t = ops.layernorm(x, gamma, beta, act=ops.ACT_SILU, M=2 * 300, x_seg=(300, 350))
+        torch.cuda.synchronize()
+        assert torch.equal(t_pl.float(), t)
+    finally:
+        ops.set_precision(old)
