@@ -223,6 +223,12 @@ int sgic_gemm_split3_f32(const float *d_A, int lda, int a_seg, int a_seg_stride,
                          const uint16_t *d_Wplanes, const float *d_bias, const float *d_R, int ldr, float *d_C, int ldc,
                          uint16_t *d_Cplanes, int M, int N, int K, int act, int c_seg, int c_seg_stride,
                          const sgic_launch_opts *opts, sgic_stream_t stream);
+/* sgic_attention_f32 with the output written as bf16x3 planes [3][rows][nheads*64] (rows = the row space of d_rowmap,
+ * >= nseq*L): the A operand of the out-projection when that runs as a split GEMM. */
+int sgic_attention_split3_f32(const float *d_q, int ldq, const float *d_k, int ldk, const float *d_v, int ldv,
+                              uint16_t *d_out_planes, long rows, int L, int nseq, int nheads, const int32_t *d_rowmap,
+                              const float *d_bias, const int32_t *d_biasvar, float scale, const sgic_launch_opts *opts,
+                              sgic_stream_t stream);
 /* nn.LayerNorm (call sites as sgic_layernorm_f32) whose only consumer is a split GEMM: the normalised rows are written
  * directly as bf16x3 planes [3][M][C] (dense rows), so no fp32 copy and no separate split pass.  C % 256 == 0, C <= 2048. */
 int sgic_layernorm_split3_f32(const float *d_x, int ldx, int xseg, int xseg_stride, const float *d_gamma,

@@ -31,6 +31,7 @@
 // dispatch slots, so K/V of a unit is fetched from HBM once and re-read from that XCD's L2.
 // q is pre-scaled by `scale` (0.125 is a power of two, so this equals scaling the scores).
 #include "common.h"
+#include "split3.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -76,6 +77,8 @@ struct AttnArgs {
   int rag;       // ragged query rows per unit computed on the VALU (0, 1 or 2): tokens nq*32 .. L-1
   int n_rag_wgs; // leading blocks that run the ragged-row path (4 rows per block)
   int stagger_cycles, first_round;  // start-up stagger of co-resident workgroups (see attn_f32_kernel), 0 = off
+  unsigned short *out_planes;       // optional: the output as bf16x3 planes [3][rows][nheads*64] (operand of the out-projection
+  long plane_elems;                 // split GEMM, gemm_split.hip) instead of `out`; rows * nheads * 64
 };
 
 __device__ __forceinline__ long at_row(const AttnArgs &a, int seq, int tok) {
@@ -135,7 +138,17 @@ __device__ void attn_ragged_row(const AttnArgs &a, int unit, int tok, float *wl 
 #pragma unroll
     for (int j = 0; j < 4; j++) acc = fmaf(p4[j], vv[j], acc);
   }
-  a.out[q_row * a.ldo + hc + lane] = acc / sum;
+  const float res = acc / sum;
+  if (a.out_planes) {
+    unsigned p1, p2, p3;
+    s3_split_pair(res, 0.f, p1, p2, p3);
+    const size_t dst = (size_t)q_row * (a.nheads * 64) + hc + lane;
+    a.out_planes[dst] = (unsigned short)p1;
+    a.out_planes[a.plane_elems + dst] = (unsigned short)p2;
+    a.out_planes[2 * a.plane_elems + dst] = (unsigned short)p3;
+  } else {
+    a.out[q_row * a.ldo + hc + lane] = res;
+  }
 }
 
 // LDS: NBUF x UP regions of one (K tile | V tile); UP = units a workgroup can span (1 when nq % ipw == 0, else 2).
@@ -426,8 +439,14 @@ __global__ __launch_bounds__(256, (NBUF * UP >= 4) ? 2 : 3) void attn_f32_kernel
       f32x4 w0, w1;
 #pragma unroll
       for (int t = 0; t < 4; t++) w0[t] = o0[g4 * 4 + t] * inv, w1[t] = o1[g4 * 4 + t] * inv;
-      *reinterpret_cast<f32x4 *>(op + d) = w0;
-      *reinterpret_cast<f32x4 *>(op + 32 + d) = w1;
+      if (a.out_planes) {
+        const size_t dst = (size_t)q_row * (a.nheads * 64) + hc + d;
+        s3_store4(a.out_planes, a.plane_elems, dst, w0);
+        s3_store4(a.out_planes, a.plane_elems, dst + 32, w1);
+      } else {
+        *reinterpret_cast<f32x4 *>(op + d) = w0;
+        *reinterpret_cast<f32x4 *>(op + 32 + d) = w1;
+      }
     }
   }
   AT_STAMP(3);
@@ -438,14 +457,15 @@ static inline void launch_attn(K kernel, unsigned grid, hipStream_t st, const At
   kernel<<<grid, 256, 0, st>>>(a);
 }
 
-extern "C" int sgic_attention_f32(const float *d_q, int ldq, const float *d_k, int ldk, const float *d_v, int ldv,
-                                  float *d_out, int ldo, int L, int nseq, int nheads, const int32_t *d_rowmap,
-                                  const float *d_bias, const int32_t *d_biasvar, float scale, const sgic_launch_opts *opts,
-                                  sgic_stream_t stream) {
-  SGIC_REQUIRE(d_q && d_k && d_v && d_out && L > 0 && nseq > 0 && nheads > 0, "args");
+static int attention_any(const float *d_q, int ldq, const float *d_k, int ldk, const float *d_v, int ldv, float *d_out, int ldo,
+                         uint16_t *d_planes, long plane_rows, int L, int nseq, int nheads, const int32_t *d_rowmap,
+                         const float *d_bias, const int32_t *d_biasvar, float scale, const sgic_launch_opts *opts,
+                         sgic_stream_t stream) {
+  SGIC_REQUIRE(d_q && d_k && d_v && (d_out || d_planes) && L > 0 && nseq > 0 && nheads > 0, "args");
   SGIC_REQUIRE((ldq & 3) == 0 && (ldk & 3) == 0 && (ldv & 3) == 0 && (ldo & 3) == 0, "row strides must be multiples of 4");
-  SGIC_REQUIRE(ldq >= nheads * 64 && ldk >= nheads * 64 && ldv >= nheads * 64 && ldo >= nheads * 64, "head_dim is 64");
-  SGIC_REQUIRE((((uintptr_t)d_q | (uintptr_t)d_k | (uintptr_t)d_v | (uintptr_t)d_out) & 15) == 0, "16-byte alignment");
+  SGIC_REQUIRE(ldq >= nheads * 64 && ldk >= nheads * 64 && ldv >= nheads * 64 && (d_planes || ldo >= nheads * 64), "head_dim is 64");
+  SGIC_REQUIRE((((uintptr_t)d_q | (uintptr_t)d_k | (uintptr_t)d_v | (uintptr_t)d_out) & 15) == 0 && ((uintptr_t)d_planes & 7) == 0, "16-byte alignment");
+  SGIC_REQUIRE(!d_planes || plane_rows >= (long)nseq * L, "plane rows");
   SGIC_REQUIRE(!d_bias || (L & 3) == 0, "bias needs L % 4 == 0");
   const int mode = opts ? opts->attn_mode : 0;
   // attn_mode: 0 = default (see below); odd = single LDS buffer (two barriers per tile), even = double-buffered LDS (one
@@ -465,7 +485,7 @@ extern "C" int sgic_attention_f32(const float *d_q, int ldq, const float *d_k, i
   const int n_rag_wgs = (int)((units * rag + 3) / 4);
   const bool up2 = (nq % ipw) != 0;
   AttnArgs a{d_q, d_k, d_v, d_out, ldq, ldk, ldv, ldo, L, nseq, nheads, d_rowmap, d_bias, d_biasvar, scale,
-             nq, ipw, (int)n_items, n_wgs, group, rag, n_rag_wgs, 0, 0};
+             nq, ipw, (int)n_items, n_wgs, group, rag, n_rag_wgs, 0, 0, d_planes, plane_rows * nheads * 64};
   const unsigned grid = (unsigned)(grid_mfma + n_rag_wgs);
   hipStream_t st = to_stream(stream);
   // default (mode 0), from the round-2 measurements (tools/bench_attn.py, tools/micro/attn_stamps.hip): a single K/V buffer
@@ -485,4 +505,24 @@ extern "C" int sgic_attention_f32(const float *d_q, int ldq, const float *d_k, i
     else launch_attn(attn_f32_kernel<2, 1>, grid, st, a);
   }
   return sgic::check_launch("attn_f32_kernel");
+}
+
+extern "C" int sgic_attention_f32(const float *d_q, int ldq, const float *d_k, int ldk, const float *d_v, int ldv,
+                                  float *d_out, int ldo, int L, int nseq, int nheads, const int32_t *d_rowmap,
+                                  const float *d_bias, const int32_t *d_biasvar, float scale, const sgic_launch_opts *opts,
+                                  sgic_stream_t stream) {
+  SGIC_REQUIRE(d_out, "out");
+  return attention_any(d_q, ldq, d_k, ldk, d_v, ldv, d_out, ldo, nullptr, 0, L, nseq, nheads, d_rowmap, d_bias, d_biasvar, scale,
+                       opts, stream);
+}
+
+// the same attention with its output written directly as bf16x3 planes [3][rows][nheads*64] (rows >= nseq*L: the row space
+// of the row map), i.e. as the A operand of the out-projection when that runs as a split GEMM
+extern "C" int sgic_attention_split3_f32(const float *d_q, int ldq, const float *d_k, int ldk, const float *d_v, int ldv,
+                                         uint16_t *d_out_planes, long rows, int L, int nseq, int nheads,
+                                         const int32_t *d_rowmap, const float *d_bias, const int32_t *d_biasvar, float scale,
+                                         const sgic_launch_opts *opts, sgic_stream_t stream) {
+  SGIC_REQUIRE(d_out_planes, "planes");
+  return attention_any(d_q, ldq, d_k, ldk, d_v, ldv, nullptr, 0, d_out_planes, rows, L, nseq, nheads, d_rowmap, d_bias, d_biasvar,
+                       scale, opts, stream);
 }

@@ -13,7 +13,10 @@ enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_TANH = 3, ACT_LRELU = 4 };
 // with the hardware reciprocal and exp2 (1 ulp each): ~14 VALU operations, branch-free.  1 + erf(z) is taken as
 // 2 - erfc(|z|) for z >= 0 and as erfc(|z|) itself for z < 0, so the negative tail has no cancellation at all
 // (max |gelu error| 4e-7 over [-12, 12], the level of the fp32 rounding of the result).
+// contract(off): the value must not depend on which epilogue instantiation the compiler inlined it into (left to itself it
+// contracts the plain multiplies / adds below differently per call site: 1-ulp differences between kernel variants).
 __device__ __forceinline__ float gelu_erf(float x) {
+#pragma clang fp contract(off)
   const float z = x * 0.70710678118654752440f;
   const float a = fabsf(z);
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.0f));

@@ -12,7 +12,10 @@ __device__ __forceinline__ unsigned s3_pk_bf16(float lo, float hi) {   // v_cvt_
   return __builtin_bit_cast(unsigned, r);
 }
 // (x0, x1) -> the three bf16 pairs; the residuals are exact in fp32 (each step removes the leading 8 bits)
+// contract(off): after inlining, the subtractions must not fuse with a multiply that produced x (the planes are the split of
+// the ROUNDED fp32 value, so a producer that writes planes and one that writes fp32 + split pass agree bit for bit)
 __device__ __forceinline__ void s3_split_pair(float x0, float x1, unsigned &p1, unsigned &p2, unsigned &p3) {
+#pragma clang fp contract(off)
   p1 = s3_pk_bf16(x0, x1);
   const float r0 = x0 - __uint_as_float(p1 << 16), r1 = x1 - __uint_as_float(p1 & 0xffff0000u);
   p2 = s3_pk_bf16(r0, r1);

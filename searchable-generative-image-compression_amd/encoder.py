@@ -40,8 +40,8 @@ def rab_forward(X, w: RabW, L, nseq, heads, bias=None):
     # split arithmetic, the plain fp32 tensor otherwise)
     h = ops.layernorm(X, w.ln1w, w.ln1b, to_gemm=True)
     qkv = ops.gemm(h, w.inw, w.inb)
-    att = h if torch.is_tensor(h) else torch.empty_like(X)   # fp32: reuse the LN buffer for the attention output
-    ops.attention(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], att, L, nseq, heads, bias=bias)
+    # the attention output reuses the LN buffer (fp32 tensor or planes)
+    att = ops.attention(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], h, L, nseq, heads, bias=bias, to_gemm=True)
     ops.gemm(att, w.ow, w.ob, residual=X, out=X)
     h = ops.layernorm(X, w.ln2w, w.ln2b, out=h, to_gemm=True)
     f = ops.gemm(h, w.fcw, w.fcb, act=ops.ACT_GELU, to_gemm=True)
@@ -111,9 +111,8 @@ def swin_forward(Fm, w: SwinW, B, H, W, win=16):
     h = ops.layernorm(Fm, w.n1w, w.n1b, to_gemm=True)
     qkv = ops.gemm(h, w.qkvw)
     nseq = B * (H // win) * (W // win)
-    att = h if torch.is_tensor(h) else torch.empty_like(Fm)
-    ops.attention(qkv[:, 0:C], qkv[:, C:2 * C], qkv[:, 2 * C:3 * C], att, win * win, nseq, C // 64, rowmap=rowmap,
-                  bias=w.bias, biasvar=var if w.shifted else None)
+    att = ops.attention(qkv[:, 0:C], qkv[:, C:2 * C], qkv[:, 2 * C:3 * C], h, win * win, nseq, C // 64, rowmap=rowmap,
+                        bias=w.bias, biasvar=var if w.shifted else None, to_gemm=True)
     ops.gemm(att, w.ow, w.ob, residual=Fm, out=Fm)
     h = ops.layernorm(Fm, w.n2w, w.n2b, out=h, to_gemm=True)
     f = ops.gemm(h, w.w0, w.b0, act=ops.ACT_GELU, to_gemm=True)

@@ -501,12 +501,22 @@ def layernorm(x, gamma, beta, out=None, eps=1e-5, act=ACT_NONE, M=None, x_seg=(0
     return out
 
 
-def attention(q, k, v, out, L, nseq, nheads, rowmap=None, bias=None, biasvar=None, scale=0.125, mode=None):
-    """q,k,v,out: 2-D row-strided views (rows x nheads*64).  mode: force attn_mode (tests / tools)."""
+def attention(q, k, v, out, L, nseq, nheads, rowmap=None, bias=None, biasvar=None, scale=0.125, mode=None, to_gemm=False):
+    """q,k,v,out: 2-D row-strided views (rows x nheads*64).  mode: force attn_mode (tests / tools).
+    to_gemm=True: the output feeds only the out-projection GEMM -> written as bf16x3 Planes over q's row space when the split
+    path is active (`out` may be None or a Planes object to reuse); otherwise into the fp32 `out` as always."""
     q, ldq = _rows(q)
     k, ldk = _rows(k)
     v, ldv = _rows(v)
-    out, ldo = _rows(out)
+    D = nheads * 64
+    pl = None
+    if to_gemm and planes_ok(D):
+        rows = q.shape[0]
+        pl = out if isinstance(out, Planes) and out.shape == (rows, D) else Planes(rows, D, q.device, buf=out.t if isinstance(out, Planes) else None)
+    else:
+        if out is None or isinstance(out, Planes):
+            out = torch.empty(q.shape[0], D, device=q.device, dtype=torch.float32)
+        out, ldo = _rows(out)
     if rowmap is not None:
         assert rowmap.dtype == torch.int32 and rowmap.numel() == nseq * L and rowmap.is_contiguous()
     if bias is not None:
@@ -515,8 +525,12 @@ def attention(q, k, v, out, L, nseq, nheads, rowmap=None, bias=None, biasvar=Non
         assert biasvar.dtype == torch.int32 and biasvar.numel() == nseq
 
     def launch(m):
-        call("sgic_attention_f32", _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), ldo, L, nseq, nheads, _p(rowmap), _p(bias),
-             _p(biasvar), float(scale), launch_opts(0, m, None))
+        if pl is not None:
+            call("sgic_attention_split3_f32", _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(pl.t), ctypes.c_long(pl.rows), L, nseq, nheads,
+                 _p(rowmap), _p(bias), _p(biasvar), float(scale), launch_opts(0, m, None))
+        else:
+            call("sgic_attention_f32", _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), ldo, L, nseq, nheads, _p(rowmap), _p(bias),
+                 _p(biasvar), float(scale), launch_opts(0, m, None))
 
     # K/V ring depth (single buffer + more workgroups per CU vs double buffer + one barrier per tile) depends on L and
     # on how many workgroups the launch has -> tuned per shape like the GEMM tiles; results are identical.
@@ -542,7 +556,7 @@ def attention(q, k, v, out, L, nseq, nheads, rowmap=None, bias=None, biasvar=Non
                             mode, best_t = cand, t
                     _remember(key, mode)
     launch(mode)
-    return out
+    return pl if pl is not None else out
 
 
 def im2col_patch(x, P, mul=1.0, add=0.0, tile16=False, out=None):

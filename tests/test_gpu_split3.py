@@ -160,3 +160,22 @@ def test_planes_producers_match_the_two_step_path(ops):
         assert torch.equal(t_pl.float(), t)
     finally:
         ops.set_precision(old)
+
+
+@pytest.mark.parametrize("L,nseq,heads", [(289, 3, 4), (256, 4, 2), (50, 5, 12), (545, 2, 3), (290, 2, 2)])
+def test_attention_planes_output(ops, L, nseq, heads):
+    """attention writing the out-projection's operand as planes == its fp32 output put through the split pass (incl. the
+    ragged VALU rows of L = 289 / 545 / 290)"""
+    g = torch.Generator(device="cuda").manual_seed(L + heads)
+    D = heads * 64
+    qkv = torch.randn(nseq * L, 3 * D, device="cuda", generator=g)
+    old = ops.PRECISION
+    ops.set_precision("split3")
+    try:
+        ref = ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], None, L, nseq, heads)
+        pl = ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], None, L, nseq, heads, to_gemm=True)
+        torch.cuda.synchronize()
+        assert isinstance(pl, ops.Planes) and torch.is_tensor(ref)
+        assert torch.equal(pl.t.view(3, nseq * L, D), ops.split3(ref))
+    finally:
+        ops.set_precision(old)
