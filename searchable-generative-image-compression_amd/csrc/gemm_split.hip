@@ -4,25 +4,25 @@
 // each fp32 operand is written as the exact sum of three bf16 values,  x = x1 + x2 + x3  (x1 = bf16(x),
 // x2 = bf16(x - x1), x3 = bf16(x - x1 - x2); 3 x 8 significant bits carry all 24 bits of an fp32), and a product as
 //     a.w  ~=  a1 w1 + (a1 w2 + a2 w1) + (a2 w2 + a1 w3 + a3 w1),
-// six v_mfma_f32_32x32x16_bf16 (fp32 accumulate; each bf16 x bf16 product is exact in fp32) for every 16 k instead of eight
-// fp32 MFMAs: 6/16 of the matrix-pipe time.  The dropped terms (a2 w3, a3 w2, a3 w3) are <= 2^-26 of the product, a
+// six v_mfma_f32_16x16x32_bf16 (fp32 accumulate; each bf16 x bf16 product is exact in fp32) per 16x16 block and 32 k instead
+// of 2 x 8 fp32 MFMAs: 6/16 of the matrix-pipe time.  The dropped terms (a2 w3, a3 w2, a3 w3) are <= 2^-26 of the product, a
 // quarter of an fp32 ulp.  Measured against an fp64 reference (tools/micro/split3_gemm.hip, K = 4096, random normal
 // data): rms error 1.01e-6 of rms(C) vs 1.14e-6 for the plain fp32 fmaf chain that gemm.hip (and any fp32 GEMM)
 // computes -- this is an fp32 GEMM in accuracy, not a reduced-precision one; tests/test_gpu_split3.py holds that bound.
 //
-// Per output element the arithmetic is a fixed sequence fixed by K alone (k slices of 32 in order, the six terms in the
-// order above inside each 16 k): no split-K, and the same for every tile shape below, so results are bitwise independent
-// of M, of the tile choice and of the batch a row sits in (batch-invariant), like gemm.hip.
+// Per output element the arithmetic is a fixed sequence fixed by K alone (k slices of 32 in order, six MFMAs per slice in the
+// term order a3w1, a1w3, a2w2, a2w1, a1w2, a1w1): no split-K, and the same for every tile shape below, so results are bitwise
+// independent of M, of the tile choice and of the batch a row sits in (batch-invariant), like gemm.hip.
 //
 // Operands arrive PRE-SPLIT as three bf16 planes [3][rows][K]: weights once at load time, activations by
 // split3_rows_kernel (or directly by the producing kernel).  The GEMM kernel is then a pure bf16 pipeline:
-//  * tile (32 WM WAVES_M) x (32 WN WAVES_N), K slices of 32, two LDS stages; rows are 64 B (32 k) unpadded, the 16-byte
-//    slot of a row is XOR-swizzled with (row >> 2) & 3: conflict-free for the ds_read_b128 lane groups
-//    {0-3,12-15,20-27},... and for ds_write_b128;
-//  * global -> VGPR -> LDS staging one slice ahead (loads issued two slices ahead), one barrier per slice; MFMA fragments
-//    double-buffered in registers; LDS writes / global loads / fragment reads interleaved one per MFMA
-//    (sched_group_barrier);
-//  * XCD-aware grouped tile walk as in gemm.hip.
+//  * tile (16 BM WAVES_M) x (16 BN WAVES_N), K slices of 32, two LDS stages; rows are 64 B (32 k) unpadded, 16-byte slots
+//    XOR-swizzled per 4-row group: conflict-free ds_read_b128 / ds_write_b128;
+//  * global -> VGPR -> LDS staging one slice ahead (loads issued two slices ahead), one barrier per slice placed where the
+//    remaining MFMAs cover the first LDS reads of the next slice (see the kernel);
+//  * XCD-aware grouped tile walk as in gemm.hip;
+//  * the 16x16x32 shape (rather than 32x32x16) keeps the dependent MFMA chain of a block at 6 x 16 cycles per 32 k, which is
+//    what the 32x32-tile latency variant for single-image requests lives on, and holds a higher clock under load.
 #include <type_traits>
 
 #include "common.h"
@@ -67,12 +67,27 @@ struct S3Args {
   int vec_epilogue;              // C / R / bias rows are float4-addressable
 };
 
-template <int WAVES_M, int WAVES_N, int WM, int WN>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void gemm_split3_kernel(S3Args g) {
-  constexpr int NT = 64 * WAVES_M * WAVES_N, TM = 32 * WM * WAVES_M, TN = 32 * WN * WAVES_N;
-  constexpr int CA = TM * 4 / NT, CW = TN * 4 / NT;   // 16-byte chunks per thread, plane and stage
-  static_assert(CA * NT == TM * 4 && CW * NT == TN * 4 && CA >= 1 && CW >= 1, "tile / thread count");
+// Tile = (16 BM WAVES_M) x (16 BN WAVES_N); every wave owns BM x BN blocks of 16 x 16 on v_mfma_f32_16x16x32_bf16 (one MFMA =
+// one plane pair over a whole 32-k slice).  The W fragment is passed as the MFMA's first operand, so a lane ends up with 4
+// CONSECUTIVE columns of one C row (row = lane & 15, columns 4 (lane >> 4) ..): the epilogue stores float4 / 8-byte plane
+// pieces straight from the accumulators, no transpose.
+//
+// Schedule of one K slice (BN >= 2; W fragments = two halves Wlo / Whi of BN/2 column blocks, held for the whole slice; A
+// fragments per block row, double-buffered):
+//     [ds_write slice kt+1 -> other LDS stage][global loads of slice kt+2]
+//     row 0:  Whi blocks (prefetched during the previous slice's tail), meanwhile read Wlo;  then Wlo blocks
+//     rows 1 .. BM-2: all blocks (A of the next row prefetched one row ahead)
+//     row BM-1: Whi blocks | BARRIER | read Whi and A row 0 of slice kt+1 from the other stage | Wlo blocks
+// i.e. the one barrier per slice sits 6 BN/2 MFMAs before the slice's end, where every LDS read of the current stage has been
+// issued, and the MFMAs left cover the latency of the first reads of the next stage: the matrix pipe never waits at the seam
+// and no fragment is held twice (acc 4 BM BN + W 12 BN + A 24 registers).
+template <int WAVES_M, int WAVES_N, int BM, int BN>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (2 * 3 * 16 * (BM * WAVES_M + BN * WAVES_N) * 64 <= 80 * 1024 && WAVES_M * WAVES_N == 8) ? 2 : 1)
+void gemm_split3_kernel(S3Args g) {
+  constexpr int NT = 64 * WAVES_M * WAVES_N, TM = 16 * BM * WAVES_M, TN = 16 * BN * WAVES_N;
+  constexpr int CA = (TM * 4 + NT - 1) / NT, CW = (TN * 4 + NT - 1) / NT;   // 16-byte chunks per thread, plane and stage
   constexpr int APLANE = TM * 64, WPLANE = TN * 64, STAGE = 3 * (APLANE + WPLANE);
+  constexpr int HB = BN >= 2 ? BN / 2 : BN;     // column blocks in the "hi" half of W (BN == 1: no halves)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN, nwg = tiles_m * tiles_n;
@@ -87,16 +102,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void gemm_split3_kernel(
     n0 = (in_group / gsz) * TN;
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave / WAVES_N) * (32 * WM), wn = (wave % WAVES_N) * (32 * WN);
-  // staging map: chunk (row = tid >> 2 + i NT/4, slot = tid & 3); NT/4 is a multiple of 16, so the swizzle term of a row
-  // does not depend on i
+  const int wm = (wave / WAVES_N) * (16 * BM), wn = (wave % WAVES_N) * (16 * BN);
+  // LDS image of a stage: per plane, rows of 64 B (32 k) unpadded; the 16-byte slot s of row r sits at slot s ^ f((r >> 2) & 3),
+  // f = (0, 2, 3, 1): conflict-free for the ds_read_b128 lane groups {0-3,12-15,20-27}, ... of a fragment read
+  // (row = lane & 15, slot = lane >> 4) and for ds_write_b128 (8 consecutive lanes = 2 whole rows)
+  auto swz = [](int row) {
+    const int gq = (row >> 2) & 3;
+    return (((gq ^ (gq >> 1)) & 1) << 1) | (gq >> 1);
+  };
+  // staging map: chunk q = tid + i NT of a plane -> (row q >> 2, slot q & 3); NT / 4 is a multiple of 16, so the swizzle of a
+  // thread's rows does not depend on i
   const int srow = tid >> 2, sslot = tid & 3;
-  const int sw = srow * 64 + ((sslot ^ ((srow >> 2) & 3)) * 16);
+  const int sw = srow * 64 + ((sslot ^ swz(srow)) * 16);
   const unsigned short *aptr[CA], *wptr[CW];
 #pragma unroll
   for (int i = 0; i < CA; i++) aptr[i] = g.A + (size_t)min(m0 + srow + i * (NT / 4), g.M - 1) * g.K + sslot * 8;
 #pragma unroll
   for (int i = 0; i < CW; i++) wptr[i] = g.W + (size_t)min(n0 + srow + i * (NT / 4), g.N - 1) * g.K + sslot * 8;
+  const bool a_on = CA * NT == TM * 4 || srow < TM, w_on = CW * NT == TN * 4 || srow < TN;   // tiles smaller than a pass
   u32x4 ra[3][CA], rw[3][CW];
   auto issue = [&](int k0) {
 #pragma unroll
@@ -111,105 +134,114 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void gemm_split3_kernel(
     unsigned char *base = smem + buf * STAGE + sw;
 #pragma unroll
     for (int p = 0; p < 3; p++) {
+      if (a_on) {
 #pragma unroll
-      for (int i = 0; i < CA; i++) *reinterpret_cast<u32x4 *>(base + p * APLANE + i * (NT / 4) * 64) = ra[p][i];
-#pragma unroll
-      for (int i = 0; i < CW; i++) *reinterpret_cast<u32x4 *>(base + 3 * APLANE + p * WPLANE + i * (NT / 4) * 64) = rw[p][i];
-    }
-  };
-  f32x16 acc[WM][WN];
-#pragma unroll
-  for (int i = 0; i < WM; i++)
-#pragma unroll
-    for (int j = 0; j < WN; j++)
-#pragma unroll
-      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
-  const int lrow = lane & 31, lhalf = lane >> 5;
-  const int lsw = (lhalf ^ ((lrow >> 2) & 3)) * 16;   // slot of sub-step 0 (k 0..15 of the slice); sub-step 1 = this ^ 32
-  const int aoff = (wm + lrow) * 64 + lsw, boff = 3 * APLANE + (wn + lrow) * 64 + lsw;
-  struct Frag {
-    bf16x8 a[3][WM], b[3][WN];
-  };
-  auto read_frag = [&](Frag &f, int buf, int s) {
-    const unsigned char *base = smem + buf * STAGE;
-#pragma unroll
-    for (int p = 0; p < 3; p++) {
-#pragma unroll
-      for (int i = 0; i < WM; i++) f.a[p][i] = *reinterpret_cast<const bf16x8 *>(base + p * APLANE + ((aoff + i * 32 * 64) ^ (s * 32)));
-#pragma unroll
-      for (int j = 0; j < WN; j++) f.b[p][j] = *reinterpret_cast<const bf16x8 *>(base + p * WPLANE + ((boff + j * 32 * 64) ^ (s * 32)));
-    }
-  };
-  auto mfma_frag = [&](const Frag &f) {   // the six terms, smallest first; THE order of the arithmetic (see the header)
-#pragma unroll
-    for (int i = 0; i < WM; i++)
-#pragma unroll
-      for (int j = 0; j < WN; j++) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[2][i], f.b[0][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0][i], f.b[2][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1][i], f.b[1][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1][i], f.b[0][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0][i], f.b[1][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0][i], f.b[0][j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < CA; i++) *reinterpret_cast<u32x4 *>(base + p * APLANE + i * (NT / 4) * 64) = ra[p][i];
       }
+      if (w_on) {
+#pragma unroll
+        for (int i = 0; i < CW; i++) *reinterpret_cast<u32x4 *>(base + 3 * APLANE + p * WPLANE + i * (NT / 4) * 64) = rw[p][i];
+      }
+    }
+  };
+  f32x4 acc[BM][BN];
+#pragma unroll
+  for (int i = 0; i < BM; i++)
+#pragma unroll
+    for (int j = 0; j < BN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int l16 = lane & 15, lq = lane >> 4;
+  // fragment address of (row base + l16, slot lq): block bases are multiples of 16 rows, so the swizzle term is the lane's own
+  const int foff = l16 * 64 + ((lq ^ swz(l16)) * 16);
+  const int aoff = wm * 64 + foff, boff = 3 * APLANE + wn * 64 + foff;
+  bf16x8 wf[3][BN], af[2][3];
+  auto read_w = [&](int buf, int j) {
+    const unsigned char *base = smem + buf * STAGE + boff + j * 16 * 64;
+#pragma unroll
+    for (int p = 0; p < 3; p++) wf[p][j] = *reinterpret_cast<const bf16x8 *>(base + p * WPLANE);
+  };
+  auto read_a = [&](int buf, int i, int set) {
+    const unsigned char *base = smem + buf * STAGE + aoff + i * 16 * 64;
+#pragma unroll
+    for (int p = 0; p < 3; p++) af[set][p] = *reinterpret_cast<const bf16x8 *>(base + p * APLANE);
+  };
+  // one 16 x 16 block over the slice: the six terms, smallest first -- THE order of the arithmetic (see the header)
+  auto block = [&](int i, int j, int set) {
+    f32x4 c = acc[i][j];
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][j], af[set][2], c, 0, 0, 0);   // a3 w1
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2][j], af[set][0], c, 0, 0, 0);   // a1 w3
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][j], af[set][1], c, 0, 0, 0);   // a2 w2
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][j], af[set][1], c, 0, 0, 0);   // a2 w1
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][j], af[set][0], c, 0, 0, 0);   // a1 w2
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][j], af[set][0], c, 0, 0, 0);   // a1 w1
+    acc[i][j] = c;
   };
   const int nk = g.K / 32;
-  Frag f0, f1;
   issue(0);
   store(0);
   if (nk > 1) issue(32);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  read_frag(f0, 0, 0);
-  // one K slice: [LDS writes of slice kt+1 | global loads of slice kt+2 | fragment reads of sub-step 1], one of each per MFMA
-  // of sub-step 0; barrier (LDS traffic only: the global loads stay in flight); the next slice's first fragments one per
-  // MFMA of sub-step 1
-  constexpr int NMF = WM * WN * 6, NLW = 3 * (CA + CW), NFR = 3 * (WM + WN);
-  auto stage = [&](int kt, auto store_c, auto issue_c) {
+  // prologue of the rotating schedule: Whi and A row 0 of slice 0
+#pragma unroll
+  for (int j = BN - HB; j < BN; j++) read_w(0, j);
+  read_a(0, 0, 0);
+  auto slice = [&](int kt, auto store_c, auto issue_c) {
     constexpr bool ST = decltype(store_c)::value, IS = decltype(issue_c)::value;
     const int cur = kt & 1, nxt = cur ^ 1;
     if constexpr (ST) store(nxt);
     if constexpr (IS) issue((kt + 2) * 32);
-    read_frag(f1, cur, 1);
-    mfma_frag(f0);
+    if constexpr (BN >= 2) {
 #pragma unroll
-    for (int i = 0; i < NMF; i++) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                 // MFMA
-      if (ST && i < NLW) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                              // DS write
-      if (i < NFR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                    // DS read
-      if (IS && i >= (NLW < NMF / 2 ? NLW : 0) && i - (NLW < NMF / 2 ? NLW : 0) < NLW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+      for (int j = 0; j < BN - HB; j++) read_w(cur, j);       // Wlo: needed after the Whi blocks of row 0
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if constexpr (ST) read_frag(f0, nxt, 0);
-    mfma_frag(f1);
-    if constexpr (ST) {
 #pragma unroll
-      for (int i = 0; i < NMF; i++) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-        if (i < NFR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+    for (int i = 0; i < BM; i++) {
+      const int set = i & 1;
+      if (i + 1 < BM) read_a(cur, i + 1, set ^ 1);
+      // rows 0 and BM-1 run their Whi blocks first
+#pragma unroll
+      for (int j = BN - HB; j < BN; j++) block(i, j, set);
+      if (i == BM - 1) {
+        // every LDS read of stage `cur` has been issued; the writes into `nxt` were issued at the top of the slice
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if constexpr (ST) {
+#pragma unroll
+          for (int j = BN - HB; j < BN; j++) read_w(nxt, j);   // Whi of the next slice (its registers are free now) ...
+          read_a(nxt, 0, BM == 1 ? 0 : (BM & 1));              // ... and A row 0, into the set row BM-1 does not use
+        }
+      }
+      if constexpr (BN >= 2) {
+#pragma unroll
+        for (int j = 0; j < BN - HB; j++) block(i, j, set);
       }
     }
   };
   {
+    static_assert((BM == 1 && BN == 1) || (BM % 2) == 0, "A row 0 of the next slice must land in set 0, free at that point");
     using T = std::true_type;
     using F = std::false_type;
     int kt = 0;
-    for (; kt + 2 < nk; ++kt) stage(kt, T{}, T{});
+    for (; kt + 2 < nk; ++kt) slice(kt, T{}, T{});
     if (kt + 1 < nk) {
-      stage(kt, T{}, F{});
+      slice(kt, T{}, F{});
       ++kt;
     }
-    stage(kt, F{}, F{});
+    slice(kt, F{}, F{});
   }
 
-  // ---- epilogue.  Accumulator layout: D[row = (e&3) + 8*(e>>2) + 4*lhalf][col = lrow].  bias -> activation -> residual,
-  // as gemm.hip.  Wide path: each wave transposes 32 rows at a time through its own LDS slice (nobody reads the staging
-  // buffers after the last barrier) and writes whole row segments, as float4 or -- when the consumer is the next GEMM --
-  // directly as bf16x3 planes (8 bytes per lane and plane).
+  // ---- epilogue: the accumulators hold C[m = block row base + l16][n = block column base + 4 lq .. + 3].  bias -> activation
+  // -> residual, as gemm.hip.  Wide path: the wave re-distributes its tile through its own LDS slice (free after the last
+  // barrier; row stride + 4 floats: conflict-free ds_write_b128) so that a store instruction writes whole row segments
+  // (16 BN floats per row), as float4 or -- when the consumer is the next GEMM -- directly as bf16x3 planes.
   if (g.vec_epilogue) {
-    constexpr int TW = 32 * WN, LPR = TW / 4, RPI = 64 / LPR, NIT = 32 / RPI;
-    float *ep = reinterpret_cast<float *>(smem) + wave * (32 * TW);
+    constexpr int RM = 16 * BM, CN = 16 * BN, LDW = CN + 4, LPR = CN / 4, RPI = 64 / LPR, NIT = RM / RPI;
+    float *ep = reinterpret_cast<float *>(smem) + wave * (RM * LDW);
+#pragma unroll
+    for (int i = 0; i < BM; i++)
+#pragma unroll
+      for (int j = 0; j < BN; j++) *reinterpret_cast<f32x4 *>(ep + (i * 16 + l16) * LDW + j * 16 + 4 * lq) = acc[i][j];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
     const int n = n0 + wn + c4;
     const bool colok = n < g.N;
@@ -219,43 +251,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void gemm_split3_kernel(
     auto run = [&](auto act_c, auto res_c, auto pl_c) {
       constexpr int ACT = decltype(act_c)::value;
       constexpr bool HASR = decltype(res_c)::value != 0, PLANES = decltype(pl_c)::value != 0;
+      constexpr int EB = NIT < 8 ? NIT : 8;    // rows in flight between the LDS read / residual load and the store
 #pragma unroll
-      for (int i = 0; i < WM; i++) {
-        f32x4 rv[NIT];
-        if constexpr (HASR) {
+      for (int b = 0; b < NIT; b += EB) {
+        f32x4 cv[EB], rv[EB];
 #pragma unroll
-          for (int it = 0; it < NIT; ++it) {
-            const int m = min(m0 + wm + i * 32 + it * RPI + r0, g.M - 1);
-            rv[it] = *reinterpret_cast<const f32x4 *>(g.R + (size_t)m * g.ldr + nc);
-          }
+        for (int q = 0; q < EB; ++q) {
+          const int rr = (b + q) * RPI + r0;
+          cv[q] = *reinterpret_cast<const f32x4 *>(ep + rr * LDW + c4);
+          if constexpr (HASR) rv[q] = *reinterpret_cast<const f32x4 *>(g.R + (size_t)min(m0 + wm + rr, g.M - 1) * g.ldr + nc);
         }
 #pragma unroll
-        for (int j = 0; j < WN; j++)
+        for (int q = 0; q < EB; ++q) {
+          const int m = m0 + wm + (b + q) * RPI + r0;
+          f32x4 v = cv[q];
 #pragma unroll
-          for (int e = 0; e < 16; e++) ep[((e & 3) + 8 * (e >> 2) + 4 * lhalf) * TW + j * 32 + lrow] = acc[i][j][e];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        constexpr int EB = NIT < 4 ? NIT : 4;
-#pragma unroll
-        for (int b = 0; b < NIT; b += EB) {
-          f32x4 cv[EB];
-#pragma unroll
-          for (int q = 0; q < EB; ++q) cv[q] = *reinterpret_cast<const f32x4 *>(ep + ((b + q) * RPI + r0) * TW + c4);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-          for (int q = 0; q < EB; ++q) {
-            const int it = b + q;
-            const int m = m0 + wm + i * 32 + it * RPI + r0;
-            f32x4 v = cv[q];
-#pragma unroll
-            for (int t = 0; t < 4; t++) v[t] = apply_act_c<ACT>(v[t] + bv[t]);
-            if constexpr (HASR) v += rv[it];
-            if (colok && m < g.M) {
-              if constexpr (PLANES) {
-                s3_store4(g.Cp, (long)g.M * g.N, (size_t)m * g.N + n, v);
-              } else {
-                const size_t crow = g.c_seg ? (size_t)(m / g.c_seg) * g.c_seg_stride + (m % g.c_seg) : (size_t)m;
-                *reinterpret_cast<f32x4 *>(g.C + crow * g.ldc + n) = v;
-              }
+          for (int t = 0; t < 4; t++) v[t] = apply_act_c<ACT>(v[t] + bv[t]);
+          if constexpr (HASR) v += rv[q];
+          if (colok && m < g.M) {
+            if constexpr (PLANES) {
+              s3_store4(g.Cp, (long)g.M * g.N, (size_t)m * g.N + n, v);
+            } else {
+              const size_t crow = g.c_seg ? (size_t)(m / g.c_seg) * g.c_seg_stride + (m % g.c_seg) : (size_t)m;
+              *reinterpret_cast<f32x4 *>(g.C + crow * g.ldc + n) = v;
             }
           }
         }
@@ -279,25 +297,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void gemm_split3_kernel(
     }
     return;
   }
-  // narrow path (N or the leading dimensions not float4-addressable): one dword per lane
+  // narrow path (N or the leading dimensions not float4-addressable): one dword at a time from the accumulators
   auto run = [&](auto act_c, auto res_c) {
     constexpr int ACT = decltype(act_c)::value;
     constexpr bool HASR = decltype(res_c)::value != 0;
 #pragma unroll
-    for (int j = 0; j < WN; j++) {
-      const int n = n0 + wn + j * 32 + lrow;
-      const bool colok = n < g.N;
-      const float bv = (g.bias && colok) ? g.bias[n] : 0.f;
+    for (int j = 0; j < BN; j++) {
+      const int n = n0 + wn + j * 16 + 4 * lq;
 #pragma unroll
-      for (int i = 0; i < WM; i++) {
+      for (int i = 0; i < BM; i++) {
+        const int m = m0 + wm + i * 16 + l16;
+        if (m >= g.M) continue;
+        const size_t crow = g.c_seg ? (size_t)(m / g.c_seg) * g.c_seg_stride + (m % g.c_seg) : (size_t)m;
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-          const int m = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
-          if (colok && m < g.M) {
-            float v = apply_act_c<ACT>(acc[i][j][e] + bv);
-            if constexpr (HASR) v += g.R[(size_t)m * g.ldr + n];
-            const size_t crow = g.c_seg ? (size_t)(m / g.c_seg) * g.c_seg_stride + (m % g.c_seg) : (size_t)m;
-            g.C[crow * g.ldc + n] = v;
+        for (int t = 0; t < 4; t++) {
+          if (n + t < g.N) {
+            float o = apply_act_c<ACT>(acc[i][j][t] + (g.bias ? g.bias[n + t] : 0.f));
+            if constexpr (HASR) o += g.R[(size_t)m * g.ldr + n + t];
+            g.C[crow * g.ldc + n + t] = o;
           }
         }
       }
@@ -329,14 +346,14 @@ extern "C" int sgic_split3_f32(const float *d_x, int ld, int rows, int cols, int
   return sgic::check_launch("split3_rows_kernel");
 }
 
-#define SGIC_SPLIT3_TILE_MODES 3
+#define SGIC_SPLIT3_TILE_MODES 5
 
-template <int WAVES_M, int WAVES_N, int WM, int WN>
+template <int WAVES_M, int WAVES_N, int BM, int BN>
 static int s3_launch(const S3Args &g, hipStream_t st, const sgic_launch_opts *o) {
-  constexpr int NT = 64 * WAVES_M * WAVES_N, TM = 32 * WM * WAVES_M, TN = 32 * WN * WAVES_N;
+  constexpr int NT = 64 * WAVES_M * WAVES_N, TM = 16 * BM * WAVES_M, TN = 16 * BN * WAVES_N;
   constexpr int LDS = 2 * 3 * (TM + TN) * 64;
   static bool attr_set = false;   // idempotent: a race sets the same value twice
-  auto kernel = gemm_split3_kernel<WAVES_M, WAVES_N, WM, WN>;
+  auto kernel = gemm_split3_kernel<WAVES_M, WAVES_N, BM, BN>;
   if (!attr_set) {
     SGIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
@@ -354,7 +371,9 @@ static int s3_launch(const S3Args &g, hipStream_t st, const sgic_launch_opts *o)
 //   d_A != NULL: A (fp32, lda, row map a_seg) is split into d_Aplanes (caller's workspace, 3*M*K bf16) first;
 //   d_A == NULL: d_Aplanes already holds the planes (written by sgic_split3_f32 or a producing kernel).
 //   d_Cplanes != NULL: the result is written as planes [3][M][N] (the A operand of the next GEMM) instead of d_C.
-// K % 32 == 0.  opts->tile_mode: 0 = heuristic, 1 = 128x256, 2 = 128x128, 3 = 64x64 tiles (bitwise identical results).
+// K % 32 == 0.  opts->tile_mode: 0 = heuristic, 1 = 128x256, 2 = 128x128, 3 = 64x64, 4 = 32x32 tiles (the latency kernel for
+// under-filled launches: 4 waves of one 16x16 block each, a dependent chain of 6 MFMAs per 32 k), 5 = 64x128 tiles with two
+// workgroups per CU (finer rounds for grids that are not a multiple of the chip); bitwise identical results.
 extern "C" int sgic_gemm_split3_f32(const float *d_A, int lda, int a_seg, int a_seg_stride, uint16_t *d_Aplanes,
                                     const uint16_t *d_Wplanes, const float *d_bias, const float *d_R, int ldr, float *d_C,
                                     int ldc, uint16_t *d_Cplanes, int M, int N, int K, int act, int c_seg, int c_seg_stride,
@@ -376,14 +395,17 @@ extern "C" int sgic_gemm_split3_f32(const float *d_A, int lda, int a_seg, int a_
   int mode = opts ? opts->tile_mode : 0;
   SGIC_REQUIRE(mode >= 0 && mode <= SGIC_SPLIT3_TILE_MODES, "tile_mode");
   if (!mode) {
-    // the largest tile whose grid still fills the 256 CUs ~twice over; launches that cannot fill the chip take 64x64
-    const long t256 = (long)((M + 127) / 128) * ((N + 255) / 256), t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    mode = t256 >= 512 ? 1 : (t128 >= 384 ? 2 : 3);
+    // the largest tile whose grid still fills the 256 CUs ~twice over; launches that cannot fill the chip take the small tiles
+    const long t256 = (long)((M + 127) / 128) * ((N + 255) / 256), t128 = (long)((M + 127) / 128) * ((N + 127) / 128),
+               t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
+    mode = t256 >= 512 ? 1 : (t128 >= 384 ? 2 : (t64 >= 256 ? 3 : 4));
   }
   hipStream_t st = to_stream(stream);
   switch (mode) {
-    case 1: return s3_launch<2, 4, 2, 2>(g, st, opts);
-    case 2: return s3_launch<2, 4, 2, 1>(g, st, opts);
-    default: return s3_launch<2, 2, 1, 1>(g, st, opts);
+    case 1: return s3_launch<2, 4, 4, 4>(g, st, opts);
+    case 2: return s3_launch<2, 4, 4, 2>(g, st, opts);
+    case 3: return s3_launch<2, 2, 2, 2>(g, st, opts);
+    case 4: return s3_launch<2, 2, 1, 1>(g, st, opts);
+    default: return s3_launch<2, 4, 2, 2>(g, st, opts);
   }
 }

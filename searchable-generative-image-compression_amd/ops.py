@@ -307,7 +307,7 @@ def _pick_and_launch(key, launch, big_enough, restore=None, modes=None):
 # pipe (csrc/gemm_split.hip).  A process-level choice (SGIC_GEMM or set_precision): which kernel family a GEMM takes may
 # depend on (N, K) and on the operands' kinds, never on M, so single-image and batched requests stay bitwise identical.
 PRECISION = os.environ.get("SGIC_GEMM", "f32")
-SPLIT3_MODES = (1, 2, 3)
+SPLIT3_MODES = (1, 2, 3, 4, 5)
 _W3 = {}          # (data_ptr, N, K, ldw, version) -> (planes, w): the weight is pinned so its address cannot be reused
 _W3_BYTES = 0
 _W3_LIMIT = 24 << 30

@@ -59,9 +59,9 @@ def test_bitwise_independent_of_tile_and_batch(ops):
     a = torch.randn(M, K, device="cuda", generator=g)
     w = torch.randn(N, K, device="cuda", generator=g) * 0.05
     bias = torch.randn(N, device="cuda", generator=g)
-    outs = [ops.gemm(a, w, bias, act=ops.ACT_GELU, precision="split3", tile=t) for t in (1, 2, 3)]
+    outs = [ops.gemm(a, w, bias, act=ops.ACT_GELU, precision="split3", tile=t) for t in (1, 2, 3, 4, 5)]
     torch.cuda.synchronize()
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
     # a single "image" (rows 289..578) computed alone == the same rows inside the batch
     one = ops.gemm(a[289:578].contiguous(), w, bias, act=ops.ACT_GELU, precision="split3")
     torch.cuda.synchronize()
@@ -77,7 +77,7 @@ def test_epilogues_vs_torch(ops, act, res):
     w = torch.randn(N, K, device="cuda", generator=g) * 0.2
     bias = torch.randn(N, device="cuda", generator=g)
     r = torch.randn(M, N, device="cuda", generator=g) if res else None
-    for tile in (1, 2, 3):
+    for tile in (1, 2, 3, 4, 5):
         out = ops.gemm(a, w, bias, residual=r, act=act, precision="split3", tile=tile)
         torch.cuda.synchronize()
         z = a.double() @ w.double().T + bias.double()
@@ -141,7 +141,7 @@ def test_planes_producers_match_the_two_step_path(ops):
         h = ops.layernorm(x, gamma, beta)
         torch.cuda.synchronize()
         assert torch.equal(h_pl.float(), h)                                 # the planes carry the fp32 value exactly
-        for tile in (1, 2, 3):
+        for tile in (1, 2, 3, 4, 5):
             f_pl = ops.gemm(h_pl, w1, b1, act=ops.ACT_GELU, to_gemm=True, tile=tile)
             f = ops.gemm(h, w1, b1, act=ops.ACT_GELU, tile=tile)
             torch.cuda.synchronize()
