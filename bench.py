@@ -27,6 +27,13 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_IMAGE = 366.3        # compress at 256x256 (355.3 enc + 2.16 bottleneck + 8.8 CLIP + VQ)
 GFLOP_PER_IMAGE_DEC = 654.3    # decompress at 256x256
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # MI355X_MICROARCH.md: ~2.5 PF dense = 1024 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+S3_MFMA_PER_MAC = 6             # csrc/gemm_split.hip: six bf16 MFMAs per fp32-equivalent multiply-add (bf16x3 split)
+PEAK_S3_TFLOPS = round(PEAK_BF16_MFMA_TFLOPS / S3_MFMA_PER_MAC, 1)   # fp32-equivalent ceiling of the split GEMM on the bf16 pipe
+
+
+def _is_s3(key):
+    return len(key) > 5 and key[5] == "s3"
 
 
 # ------------------------------------------------------------------------------------------------ launcher
@@ -182,7 +189,8 @@ def rehearse_cpu(args, world, rank):
 
 # ------------------------------------------------------------------------------------------------ roofline helpers
 def by_shape_table(prof, ops, dev, top=10):
-    """per-shape roofline of the dominant kernel from the per-launch event pairs of the timed region"""
+    """per-shape roofline of the GEMM launches from the per-launch event pairs of the timed region; `frac` is against the
+    peak of the kernel the shape ran on (split GEMM: bf16 peak / 6; fp32 MFMA kernel: 157.3)"""
     agg = {}
     for fl, ms, key in prof:
         v = agg.setdefault(key, [0.0, 0.0, 0])
@@ -202,38 +210,61 @@ def by_shape_table(prof, ops, dev, top=10):
         else:
             nb = 1
             M, N, K, res, act = key[:5]
-        algo = 4.0 * nb * (M * K + N * K + M * N * (2 if res else 1))
-        r = {"M": M, "N": N, "K": K, "batch": nb, "residual": bool(res), "act": act, "calls": v[2],
-             "tflops": round(v[0] / v[1] / 1e9, 1), "frac": round(v[0] / v[1] / 1e9 / PEAK_FP32_MFMA_TFLOPS, 3),
+        s3 = _is_s3(key)
+        # algorithmic bytes: fp32 operands and result; the split kernel reads its operands as 3 bf16 planes (6 B per element)
+        algo = (6.0 if s3 else 4.0) * nb * (M * K + N * K) + 4.0 * nb * M * N * (2 if res else 1)
+        peak = PEAK_S3_TFLOPS if s3 else PEAK_FP32_MFMA_TFLOPS
+        r = {"M": M, "N": N, "K": K, "batch": nb, "residual": bool(res), "act": act, "calls": v[2], "kernel": "split3" if s3 else "f32",
+             "tflops": round(v[0] / v[1] / 1e9, 1), "frac": round(v[0] / v[1] / 1e9 / peak, 3),
              "share_of_gemm_time": round(v[1] / total_ms, 4), "avg_us": round(v[1] / v[2] * 1e3, 1),
              "algorithmic_MB": round(algo / 1e6, 1), "tile_mode": ops.tile_of(key, dev)}
         p = pmc.get((M, N, K))
-        if p:
+        if p and p.get("kernel", "f32") == r["kernel"]:
             r["counter_MB"] = p["counter_MB"]
         rows.append(r)
     return rows
 
 
 def roofline_block(prof, ops, dev, dt, steps, flops_per_step, pmc_file):
-    gemm_flops = sum(p[0] for p in prof)
-    gemm_ms = sum(p[1] for p in prof)
-    n_launch = len(prof)
+    """dominant kernel = the GEMM family that holds most of the GEMM time: the bf16x3 split GEMM (priced against the bf16 dense
+    MFMA peak / 6 MFMAs per multiply-add) or the fp32-input MFMA GEMM (157.3)"""
+    s3 = [p for p in prof if _is_s3(p[2])]
+    f32 = [p for p in prof if not _is_s3(p[2])]
+    dom_s3 = sum(p[1] for p in s3) > sum(p[1] for p in f32)
+    dom, other = (s3, f32) if dom_s3 else (f32, s3)
+    peak = PEAK_S3_TFLOPS if dom_s3 else PEAK_FP32_MFMA_TFLOPS
+    gemm_flops = sum(p[0] for p in dom)
+    gemm_ms = sum(p[1] for p in dom)
+    all_ms = sum(p[1] for p in prof)
+    n_launch = len(dom)
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     traffic = None
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
-        traffic = int((pj["hbm_fetch_MB_per_launch_x2_corrected"] + pj["hbm_write_MB_per_launch"]) * 1e6)
+        if pj.get("kernel", "gemm_f32_kernel") == ("gemm_split3_kernel" if dom_s3 else "gemm_f32_kernel"):
+            traffic = int((pj["hbm_fetch_MB_per_launch_x2_corrected"] + pj["hbm_write_MB_per_launch"]) * 1e6)
     except Exception:
         pass
-    return {"bound": "mfma", "kernel": "gemm_f32_kernel", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-            "traffic_unit": f"bytes per launch (rocprofv3 PMC, profiles/{pmc_file})",
-            "launches_per_step": n_launch // max(1, steps),
-            "avg_launch_us": round(gemm_ms * 1e3 / max(1, n_launch), 2),
-            "gflop_per_launch": round(gemm_flops / max(1, n_launch) / 1e9, 3),
-            "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 4),
-            "end_to_end_frac": round(flops_per_step * steps / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-            "by_shape": by_shape_table(prof, ops, dev)}
+    blk = {"bound": "mfma", "kernel": "gemm_split3_kernel" if dom_s3 else "gemm_f32_kernel", "achieved": round(achieved, 2), "peak": peak,
+           "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+           "traffic_unit": f"bytes per launch (rocprofv3 PMC, profiles/{pmc_file})",
+           "launches_per_step": n_launch // max(1, steps),
+           "avg_launch_us": round(gemm_ms * 1e3 / max(1, n_launch), 2),
+           "gflop_per_launch": round(gemm_flops / max(1, n_launch) / 1e9, 3),
+           "gemm_share_of_step": round(all_ms / (dt * 1e3), 4),
+           "end_to_end_frac": round(flops_per_step * steps / dt / 1e12 / peak, 4),
+           "by_shape": by_shape_table(prof, ops, dev)}
+    if dom_s3:
+        blk["peak_note"] = (f"fp32-equivalent ceiling of the bf16x3 split GEMM: bf16 dense MFMA peak {PEAK_BF16_MFMA_TFLOPS} TFLOP/s / "
+                            f"{S3_MFMA_PER_MAC} bf16 MFMAs per multiply-add; `achieved` counts ALGORITHMIC fp32 flops (2 M N K)")
+        blk["bf16_mfma_tflops"] = round(achieved * S3_MFMA_PER_MAC, 1)
+        blk["frac_of_fp32_mfma_peak"] = round(achieved / PEAK_FP32_MFMA_TFLOPS, 4)
+    if other:
+        oms = sum(p[1] for p in other)
+        blk["other_gemm_kernel"] = {"kernel": "gemm_f32_kernel" if dom_s3 else "gemm_split3_kernel", "launches_per_step": len(other) // max(1, steps),
+                                    "achieved": round(sum(p[0] for p in other) / (oms * 1e-3) / 1e12, 2) if oms > 0 else 0.0,
+                                    "peak": PEAK_FP32_MFMA_TFLOPS if dom_s3 else PEAK_S3_TFLOPS, "share_of_gemm_time": round(oms / all_ms, 4) if all_ms else 0.0}
+    return blk
 
 
 # ------------------------------------------------------------------------------------------------ the bench
@@ -402,6 +433,9 @@ def main():
             "value": round(world * B * args.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "arithmetic": ("f32 results; GEMMs as bf16x3 split on the bf16 matrix pipe (3 bf16 pieces per fp32 operand, 6 MFMAs per multiply-add, "
+                           "fp32 accumulate; error vs fp64 <= the fp32 fmaf chain's, tests/test_gpu_split3.py), attention / norms / entropy in f32"
+                           if ops.PRECISION == "split3" else "f32 throughout (fp32-input MFMA GEMMs)"),
             "config": {"workload": (f"configs[1]: batch={B} {S}x{S} encoder+entropy+CLIP compress per GPU, "
                                     f"{'SMALL debug model' if args.small else 'TiTok ViT-L hybrid encoder + ViT-B/32 CLIP'}, synthetic weights")
                        if not dec_primary else
@@ -434,6 +468,29 @@ def main():
                 "roofline": roofline_block(dprof, ops, dev, ddt, args.secondary_steps,
                                            GFLOP_PER_IMAGE_DEC * (S / 256.0) ** 2 * 1e9 * B,
                                            "round2_pmc_decompress_gemm_summary.json")}}
+        if world == 1 and not dec_primary and not args.no_secondary and ops.PRECISION == "split3":
+            # the same compress step with every GEMM on the exact-fp32 MFMA kernel (SGIC_GEMM=f32), for reference
+            ops.set_precision("f32")
+            try:
+                for _ in range(2):
+                    step()
+                drain()
+                ops.profile_begin()
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(args.secondary_steps):
+                    step()
+                drain()
+                sync()
+                fdt = time.perf_counter() - t0
+                fprof = ops.profile_end()
+            finally:
+                ops.set_precision("split3")
+            res["secondary"]["compress_f32_mfma"] = {
+                "metric": "images/sec end-to-end compress at 256x256 with SGIC_GEMM=f32 (every GEMM on v_mfma_f32_32x32x2_f32)",
+                "value": round(B * args.secondary_steps / fdt, 3), "unit": "images/s", "steps": args.secondary_steps,
+                "ms_per_step": round(fdt / args.secondary_steps * 1e3, 3),
+                "roofline": roofline_block(fprof, ops, dev, fdt, args.secondary_steps, gflop * 1e9 * B, "round2_pmc_gemm_summary.json")}
         if world == 1 and not args.no_cpu_baseline and not args.small and not dec_primary:
             res["cpu_baseline"] = cpu_baseline(sd, clip_sd, cfg, clip_cfg)
         print(json.dumps(res), flush=True)

@@ -162,7 +162,8 @@ def tile_of(key, dev=None):
     if key and key[0] == "conv3x3":
         return _TILE.get(key)
     M, N, K, res, act = key[:5]
-    return _TILE.get(("gemm", M, N, K, int(bool(res)), act))
+    kind = "gemm3" if len(key) > 5 and key[5] == "s3" else "gemm"
+    return _TILE.get((kind, M, N, K, int(bool(res)), act))
 
 
 _load_tile_cache()
@@ -306,7 +307,8 @@ def _pick_and_launch(key, launch, big_enough, restore=None, modes=None):
 # ---- GEMM arithmetic: "f32" = the exact-fp32 MFMA (csrc/gemm.hip), "split3" = fp32-accurate bf16x3 split on the bf16 matrix
 # pipe (csrc/gemm_split.hip).  A process-level choice (SGIC_GEMM or set_precision): which kernel family a GEMM takes may
 # depend on (N, K) and on the operands' kinds, never on M, so single-image and batched requests stay bitwise identical.
-PRECISION = os.environ.get("SGIC_GEMM", "f32")
+PRECISION = os.environ.get("SGIC_GEMM", "split3")
+assert PRECISION in ("f32", "split3"), f"SGIC_GEMM={PRECISION!r}: expected f32 or split3"
 SPLIT3_MODES = (1, 2, 3, 4, 5)
 _W3 = {}          # (data_ptr, N, K, ldw, version) -> (planes, w): the weight is pinned so its address cannot be reused
 _W3_BYTES = 0
@@ -460,7 +462,7 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(
             if _pick_and_launch(key, launch3, M * N >= (1 << 16), restore=out if inplace else None, modes=SPLIT3_MODES):
                 return out_planes if out_planes is not None else out
         if PROFILE is not None:
-            PROFILE.append((2.0 * M * N * K, (M, N, K, residual is not None, act)))
+            PROFILE.append((2.0 * M * N * K, (M, N, K, residual is not None, act, "s3")))
         return out_planes if out_planes is not None else out
 
     def launch(mode, prof=None):
