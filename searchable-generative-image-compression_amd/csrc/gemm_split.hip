@@ -56,6 +56,14 @@ __global__ __launch_bounds__(256) void split3_rows_kernel(const float *__restric
   }
 }
 
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void s3_for(F &&f) {   // f(IntC<0>) ... f(IntC<N-1>): compile-time indices for the register sets
+  if constexpr (I < N) {
+    f(IntC<I>{});
+    s3_for<N, I + 1>(f);
+  }
+}
+
 struct S3Args {
   const unsigned short *A, *W;   // planes [3][M][K], [3][N][K]
   const float *bias, *R;
@@ -81,7 +89,10 @@ struct S3Args {
 // i.e. the one barrier per slice sits 6 BN/2 MFMAs before the slice's end, where every LDS read of the current stage has been
 // issued, and the MFMAs left cover the latency of the first reads of the next stage: the matrix pipe never waits at the seam
 // and no fragment is held twice (acc 4 BM BN + W 12 BN + A 24 registers).
-template <int WAVES_M, int WAVES_N, int BM, int BN>
+// NS = register sets of staged K slices: 1 = loads run two slices ahead (large tiles: a slice is >= 1536 MFMA cycles, longer than a
+// load); NS > 1 = the loads of slice kt + 1 + NS are issued at slice kt (small tiles of under-filled launches: a slice is 100-400
+// MFMA cycles and one workgroup per CU has nothing else to hide a ~2 us load behind).
+template <int WAVES_M, int WAVES_N, int BM, int BN, int NS>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (2 * 3 * 16 * (BM * WAVES_M + BN * WAVES_N) * 64 <= 80 * 1024 && WAVES_M * WAVES_N == 8) ? 2 : 1)
 void gemm_split3_kernel(S3Args g) {
   constexpr int NT = 64 * WAVES_M * WAVES_N, TM = 16 * BM * WAVES_M, TN = 16 * BN * WAVES_N;
@@ -120,27 +131,29 @@ void gemm_split3_kernel(S3Args g) {
 #pragma unroll
   for (int i = 0; i < CW; i++) wptr[i] = g.W + (size_t)min(n0 + srow + i * (NT / 4), g.N - 1) * g.K + sslot * 8;
   const bool a_on = CA * NT == TM * 4 || srow < TM, w_on = CW * NT == TN * 4 || srow < TN;   // tiles smaller than a pass
-  u32x4 ra[3][CA], rw[3][CW];
-  auto issue = [&](int k0) {
+  u32x4 ra[NS][3][CA], rw[NS][3][CW];
+  auto issue = [&](int k0, auto set_c) {
+    constexpr int S = decltype(set_c)::value;
 #pragma unroll
     for (int p = 0; p < 3; p++) {
 #pragma unroll
-      for (int i = 0; i < CA; i++) ra[p][i] = *reinterpret_cast<const u32x4 *>(aptr[i] + p * g.a_plane + k0);
+      for (int i = 0; i < CA; i++) ra[S][p][i] = *reinterpret_cast<const u32x4 *>(aptr[i] + p * g.a_plane + k0);
 #pragma unroll
-      for (int i = 0; i < CW; i++) rw[p][i] = *reinterpret_cast<const u32x4 *>(wptr[i] + p * g.w_plane + k0);
+      for (int i = 0; i < CW; i++) rw[S][p][i] = *reinterpret_cast<const u32x4 *>(wptr[i] + p * g.w_plane + k0);
     }
   };
-  auto store = [&](int buf) {
+  auto store = [&](int buf, auto set_c) {
+    constexpr int S = decltype(set_c)::value;
     unsigned char *base = smem + buf * STAGE + sw;
 #pragma unroll
     for (int p = 0; p < 3; p++) {
       if (a_on) {
 #pragma unroll
-        for (int i = 0; i < CA; i++) *reinterpret_cast<u32x4 *>(base + p * APLANE + i * (NT / 4) * 64) = ra[p][i];
+        for (int i = 0; i < CA; i++) *reinterpret_cast<u32x4 *>(base + p * APLANE + i * (NT / 4) * 64) = ra[S][p][i];
       }
       if (w_on) {
 #pragma unroll
-        for (int i = 0; i < CW; i++) *reinterpret_cast<u32x4 *>(base + 3 * APLANE + p * WPLANE + i * (NT / 4) * 64) = rw[p][i];
+        for (int i = 0; i < CW; i++) *reinterpret_cast<u32x4 *>(base + 3 * APLANE + p * WPLANE + i * (NT / 4) * 64) = rw[S][p][i];
       }
     }
   };
@@ -176,20 +189,26 @@ void gemm_split3_kernel(S3Args g) {
     acc[i][j] = c;
   };
   const int nk = g.K / 32;
-  issue(0);
-  store(0);
-  if (nk > 1) issue(32);
+  issue(0, IntC<0>{});
+  store(0, IntC<0>{});
+  if constexpr (NS == 1) {
+    if (nk > 1) issue(32, IntC<0>{});
+  } else {
+    // slices 1 .. NS into sets 1 .. NS-1, 0 (slice j lives in set j % NS; set 0 was just stored)
+    s3_for<NS>([&](auto u_c) {
+      constexpr int J = decltype(u_c)::value + 1;
+      if (J < nk) issue(J * 32, IntC<J % NS>{});
+    });
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   // prologue of the rotating schedule: Whi and A row 0 of slice 0
 #pragma unroll
   for (int j = BN - HB; j < BN; j++) read_w(0, j);
   read_a(0, 0, 0);
-  auto slice = [&](int kt, auto store_c, auto issue_c) {
-    constexpr bool ST = decltype(store_c)::value, IS = decltype(issue_c)::value;
-    const int cur = kt & 1, nxt = cur ^ 1;
-    if constexpr (ST) store(nxt);
-    if constexpr (IS) issue((kt + 2) * 32);
+  // MFMA part of a slice; `more` = a next slice exists (its first fragments are read behind the barrier)
+  auto compute = [&](int cur, bool more) {
+    const int nxt = cur ^ 1;
     if constexpr (BN >= 2) {
 #pragma unroll
       for (int j = 0; j < BN - HB; j++) read_w(cur, j);       // Wlo: needed after the Whi blocks of row 0
@@ -205,7 +224,7 @@ void gemm_split3_kernel(S3Args g) {
         // every LDS read of stage `cur` has been issued; the writes into `nxt` were issued at the top of the slice
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if constexpr (ST) {
+        if (more) {
 #pragma unroll
           for (int j = BN - HB; j < BN; j++) read_w(nxt, j);   // Whi of the next slice (its registers are free now) ...
           read_a(nxt, 0, BM == 1 ? 0 : (BM & 1));              // ... and A row 0, into the set row BM-1 does not use
@@ -217,8 +236,14 @@ void gemm_split3_kernel(S3Args g) {
       }
     }
   };
-  {
-    static_assert((BM == 1 && BN == 1) || (BM % 2) == 0, "A row 0 of the next slice must land in set 0, free at that point");
+  static_assert((BM == 1 && BN == 1) || (BM % 2) == 0, "A row 0 of the next slice must land in set 0, free at that point");
+  if constexpr (NS == 1) {
+    auto slice = [&](int kt, auto store_c, auto issue_c) {
+      constexpr bool ST = decltype(store_c)::value, IS = decltype(issue_c)::value;
+      if constexpr (ST) store((kt & 1) ^ 1, IntC<0>{});
+      if constexpr (IS) issue((kt + 2) * 32, IntC<0>{});
+      compute(kt & 1, ST);
+    };
     using T = std::true_type;
     using F = std::false_type;
     int kt = 0;
@@ -228,6 +253,21 @@ void gemm_split3_kernel(S3Args g) {
       ++kt;
     }
     slice(kt, F{}, F{});
+  } else {
+    for (int base = 0; base < nk; base += NS) {
+      s3_for<NS>([&](auto u_c) {
+        constexpr int U = decltype(u_c)::value;
+        const int kt = base + U;              // base % NS == 0: slice kt + 1 lives in set (U + 1) % NS
+        if (kt < nk) {                        // uniform
+          const bool more = kt + 1 < nk;
+          if (more) {
+            store((kt & 1) ^ 1, IntC<(U + 1) % NS>{});
+            if (kt + 1 + NS < nk) issue((kt + 1 + NS) * 32, IntC<(U + 1) % NS>{});
+          }
+          compute(kt & 1, more);
+        }
+      });
+    }
   }
 
   // ---- epilogue: the accumulators hold C[m = block row base + l16][n = block column base + 4 lq .. + 3].  bias -> activation
@@ -348,12 +388,12 @@ extern "C" int sgic_split3_f32(const float *d_x, int ld, int rows, int cols, int
 
 #define SGIC_SPLIT3_TILE_MODES 5
 
-template <int WAVES_M, int WAVES_N, int BM, int BN>
+template <int WAVES_M, int WAVES_N, int BM, int BN, int NS>
 static int s3_launch(const S3Args &g, hipStream_t st, const sgic_launch_opts *o) {
   constexpr int NT = 64 * WAVES_M * WAVES_N, TM = 16 * BM * WAVES_M, TN = 16 * BN * WAVES_N;
   constexpr int LDS = 2 * 3 * (TM + TN) * 64;
   static bool attr_set = false;   // idempotent: a race sets the same value twice
-  auto kernel = gemm_split3_kernel<WAVES_M, WAVES_N, BM, BN>;
+  auto kernel = gemm_split3_kernel<WAVES_M, WAVES_N, BM, BN, NS>;
   if (!attr_set) {
     SGIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
@@ -402,10 +442,10 @@ extern "C" int sgic_gemm_split3_f32(const float *d_A, int lda, int a_seg, int a_
   }
   hipStream_t st = to_stream(stream);
   switch (mode) {
-    case 1: return s3_launch<2, 4, 4, 4>(g, st, opts);
-    case 2: return s3_launch<2, 4, 4, 2>(g, st, opts);
-    case 3: return s3_launch<2, 2, 2, 2>(g, st, opts);
-    case 4: return s3_launch<2, 2, 1, 1>(g, st, opts);
-    default: return s3_launch<2, 4, 2, 2>(g, st, opts);
+    case 1: return s3_launch<2, 4, 4, 4, 1>(g, st, opts);
+    case 2: return s3_launch<2, 4, 4, 2, 1>(g, st, opts);
+    case 3: return s3_launch<2, 2, 2, 2, 4>(g, st, opts);
+    case 4: return s3_launch<2, 2, 1, 1, 6>(g, st, opts);
+    default: return s3_launch<2, 4, 2, 2, 1>(g, st, opts);
   }
 }

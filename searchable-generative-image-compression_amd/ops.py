@@ -394,7 +394,8 @@ def _a3_workspace(dev, n_u16):
 
 
 def _stream_key():
-    return torch.cuda.current_stream().cuda_stream
+    from ._lib import stream
+    return stream().value
 
 
 def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(0, 0), c_seg=(0, 0), tile=None, w_const=True,
