@@ -72,6 +72,7 @@ struct S3Args {
   int c_seg, c_seg_stride;
   long a_plane, w_plane;         // elements between planes
   unsigned short *Cp;            // optional: the result as bf16x3 planes [3][M][N] (the next GEMM's A operand) instead of C
+  long c_plane;                  // elements between the planes of Cp
   int vec_epilogue;              // C / R / bias rows are float4-addressable
 };
 
@@ -310,7 +311,7 @@ void gemm_split3_kernel(S3Args g) {
           if constexpr (HASR) v += rv[q];
           if (colok && m < g.M) {
             if constexpr (PLANES) {
-              s3_store4(g.Cp, (long)g.M * g.N, (size_t)m * g.N + n, v);
+              s3_store4(g.Cp, g.c_plane, (size_t)m * g.N + n, v);
             } else {
               const size_t crow = g.c_seg ? (size_t)(m / g.c_seg) * g.c_seg_stride + (m % g.c_seg) : (size_t)m;
               *reinterpret_cast<f32x4 *>(g.C + crow * g.ldc + n) = v;
@@ -386,10 +387,10 @@ extern "C" int sgic_split3_f32(const float *d_x, int ld, int rows, int cols, int
   return sgic::check_launch("split3_rows_kernel");
 }
 
-#define SGIC_SPLIT3_TILE_MODES 5
+#define SGIC_SPLIT3_TILE_MODES 7
 
 template <int WAVES_M, int WAVES_N, int BM, int BN, int NS>
-static int s3_launch(const S3Args &g, hipStream_t st, const sgic_launch_opts *o) {
+static int s3_launch(const S3Args &g, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
   constexpr int NT = 64 * WAVES_M * WAVES_N, TM = 16 * BM * WAVES_M, TN = 16 * BN * WAVES_N;
   constexpr int LDS = 2 * 3 * (TM + TN) * 64;
   static bool attr_set = false;   // idempotent: a race sets the same value twice
@@ -399,12 +400,22 @@ static int s3_launch(const S3Args &g, hipStream_t st, const sgic_launch_opts *o)
     attr_set = true;
   }
   const dim3 grid((unsigned)(((g.M + TM - 1) / TM) * ((g.N + TN - 1) / TN)));
-  if (const auto *evp = prof_next(o)) {
-    hipExtLaunchKernelGGL(kernel, grid, dim3(NT), LDS, st, evp->first, evp->second, 0, g);
+  if (ev_start || ev_stop) {
+    hipExtLaunchKernelGGL(kernel, grid, dim3(NT), LDS, st, ev_start, ev_stop, 0, g);
   } else {
     kernel<<<grid, NT, LDS, st>>>(g);
   }
   return sgic::check_launch("gemm_split3_kernel");
+}
+
+static int s3_mode(const S3Args &g, int mode, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+  switch (mode) {
+    case 1: return s3_launch<2, 4, 4, 4, 1>(g, st, e0, e1);
+    case 2: return s3_launch<2, 4, 4, 2, 1>(g, st, e0, e1);
+    case 3: return s3_launch<2, 2, 2, 2, 4>(g, st, e0, e1);
+    case 4: return s3_launch<2, 2, 1, 1, 6>(g, st, e0, e1);
+    default: return s3_launch<2, 4, 2, 2, 1>(g, st, e0, e1);
+  }
 }
 
 // C[M,N] = act(A . W^T + bias) + R with both operands as bf16x3 planes (see the header of this file).
@@ -413,7 +424,8 @@ static int s3_launch(const S3Args &g, hipStream_t st, const sgic_launch_opts *o)
 //   d_Cplanes != NULL: the result is written as planes [3][M][N] (the A operand of the next GEMM) instead of d_C.
 // K % 32 == 0.  opts->tile_mode: 0 = heuristic, 1 = 128x256, 2 = 128x128, 3 = 64x64, 4 = 32x32 tiles (the latency kernel for
 // under-filled launches: 4 waves of one 16x16 block each, a dependent chain of 6 MFMAs per 32 k), 5 = 64x128 tiles with two
-// workgroups per CU (finer rounds for grids that are not a multiple of the chip); bitwise identical results.
+// workgroups per CU (finer rounds for grids that are not a multiple of the chip), 6 / 7 = 1 / 2 for the rows that fill whole rounds
+// of the chip + mode 5 for the remaining rows (two launches); bitwise identical results.
 extern "C" int sgic_gemm_split3_f32(const float *d_A, int lda, int a_seg, int a_seg_stride, uint16_t *d_Aplanes,
                                     const uint16_t *d_Wplanes, const float *d_bias, const float *d_R, int ldr, float *d_C,
                                     int ldc, uint16_t *d_Cplanes, int M, int N, int K, int act, int c_seg, int c_seg_stride,
@@ -431,7 +443,7 @@ extern "C" int sgic_gemm_split3_f32(const float *d_A, int lda, int a_seg, int a_
   const int vec = (N % 4 == 0) && (!d_bias || ((uintptr_t)d_bias & 15) == 0) && (!d_R || ((ldr % 4 == 0) && ((uintptr_t)d_R & 15) == 0)) &&
                   (d_Cplanes ? ((uintptr_t)d_Cplanes & 7) == 0 : ((ldc % 4 == 0) && ((uintptr_t)d_C & 15) == 0));
   SGIC_REQUIRE(!d_Cplanes || (vec && c_seg == 0), "planes output needs float4-addressable operands and no row map");
-  S3Args g{d_Aplanes, d_Wplanes, d_bias, d_R, d_C, M, N, K, ldr, ldc, act, c_seg, c_seg_stride, (long)M * K, (long)N * K, d_Cplanes, vec};
+  S3Args g{d_Aplanes, d_Wplanes, d_bias, d_R, d_C, M, N, K, ldr, ldc, act, c_seg, c_seg_stride, (long)M * K, (long)N * K, d_Cplanes, (long)M * N, vec};
   int mode = opts ? opts->tile_mode : 0;
   SGIC_REQUIRE(mode >= 0 && mode <= SGIC_SPLIT3_TILE_MODES, "tile_mode");
   if (!mode) {
@@ -441,11 +453,29 @@ extern "C" int sgic_gemm_split3_f32(const float *d_A, int lda, int a_seg, int a_
     mode = t256 >= 512 ? 1 : (t128 >= 384 ? 2 : (t64 >= 256 ? 3 : 4));
   }
   hipStream_t st = to_stream(stream);
-  switch (mode) {
-    case 1: return s3_launch<2, 4, 4, 4, 1>(g, st, opts);
-    case 2: return s3_launch<2, 4, 4, 2, 1>(g, st, opts);
-    case 3: return s3_launch<2, 2, 2, 2, 4>(g, st, opts);
-    case 4: return s3_launch<2, 2, 1, 1, 6>(g, st, opts);
-    default: return s3_launch<2, 4, 2, 2, 1>(g, st, opts);
+  const auto *evp = prof_next(opts);
+  hipEvent_t e0 = evp ? evp->first : nullptr, e1 = evp ? evp->second : nullptr;
+  if (mode >= 6) {
+    // modes 6 / 7 = modes 1 / 2 for the rows that fill WHOLE rounds of the 256 CUs + the 64x128 two-per-CU tiles for the rest,
+    // as two launches (the first ends on a full round, so nothing idles at the seam): a last round of big tiles that covers a
+    // fraction of the chip costs a whole tile time, the small tiles finish it in about half.  One profiler record spans both.
+    const int big = mode - 5, TM = 128, TN = big == 1 ? 256 : 128;
+    const long tiles_n = (N + TN - 1) / TN, tiles_m = (M + TM - 1) / TM;
+    const long m_full = (tiles_m * tiles_n / 256) * 256 / tiles_n;   // m-tiles inside whole rounds
+    const long m_split = m_full * TM;
+    if (m_full > 0 && m_split < M && c_seg == 0) {
+      S3Args g1 = g, g2 = g;
+      g1.M = (int)m_split;
+      g2.M = M - (int)m_split;
+      g2.A += m_split * K;
+      if (g2.C) g2.C += m_split * ldc;
+      if (g2.R) g2.R += m_split * ldr;
+      if (g2.Cp) g2.Cp += m_split * N;
+      int rc = s3_mode(g1, big, st, e0, nullptr);
+      if (rc) return rc;
+      return s3_mode(g2, 5, st, nullptr, e1);
+    }
+    mode = big;
   }
+  return s3_mode(g, mode, st, e0, e1);
 }

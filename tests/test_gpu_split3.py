@@ -55,17 +55,18 @@ def test_error_not_above_fp32_path(ops, M, N, K):
 
 def test_bitwise_independent_of_tile_and_batch(ops):
     g = torch.Generator(device="cuda").manual_seed(11)
-    M, N, K = 1100, 768, 1024
+    M, N, K = 12000, 768, 1024      # 94 x 3 tiles of 128x256: one whole round of the 256 CUs + a tail (modes 6 / 7 split at row 10880)
     a = torch.randn(M, K, device="cuda", generator=g)
     w = torch.randn(N, K, device="cuda", generator=g) * 0.05
     bias = torch.randn(N, device="cuda", generator=g)
-    outs = [ops.gemm(a, w, bias, act=ops.ACT_GELU, precision="split3", tile=t) for t in (1, 2, 3, 4, 5)]
+    outs = [ops.gemm(a, w, bias, act=ops.ACT_GELU, precision="split3", tile=t) for t in (1, 2, 3, 4, 5, 6, 7)]
     torch.cuda.synchronize()
     assert all(torch.equal(outs[0], o) for o in outs[1:])
     # a single "image" (rows 289..578) computed alone == the same rows inside the batch
     one = ops.gemm(a[289:578].contiguous(), w, bias, act=ops.ACT_GELU, precision="split3")
+    tail = ops.gemm(a[11000:].contiguous(), w, bias, act=ops.ACT_GELU, precision="split3", tile=6)
     torch.cuda.synchronize()
-    assert torch.equal(one, outs[0][289:578])
+    assert torch.equal(one, outs[0][289:578]) and torch.equal(tail, outs[0][11000:])
 
 
 @pytest.mark.parametrize("act", [0, 1, 2, 3, 4])
@@ -77,7 +78,7 @@ def test_epilogues_vs_torch(ops, act, res):
     w = torch.randn(N, K, device="cuda", generator=g) * 0.2
     bias = torch.randn(N, device="cuda", generator=g)
     r = torch.randn(M, N, device="cuda", generator=g) if res else None
-    for tile in (1, 2, 3, 4, 5):
+    for tile in (1, 2, 3, 4, 5, 6, 7):
         out = ops.gemm(a, w, bias, residual=r, act=act, precision="split3", tile=tile)
         torch.cuda.synchronize()
         z = a.double() @ w.double().T + bias.double()
@@ -141,7 +142,7 @@ def test_planes_producers_match_the_two_step_path(ops):
         h = ops.layernorm(x, gamma, beta)
         torch.cuda.synchronize()
         assert torch.equal(h_pl.float(), h)                                 # the planes carry the fp32 value exactly
-        for tile in (1, 2, 3, 4, 5):
+        for tile in (1, 2, 3, 4, 5, 6, 7):
             f_pl = ops.gemm(h_pl, w1, b1, act=ops.ACT_GELU, to_gemm=True, tile=tile)
             f = ops.gemm(h, w1, b1, act=ops.ACT_GELU, tile=tile)
             torch.cuda.synchronize()
