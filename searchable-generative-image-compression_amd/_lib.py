@@ -6,7 +6,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libsgic.so")
+_SO = os.environ.get("SGIC_LIB") or os.path.join(_HERE, "libsgic.so")   # SGIC_LIB: A/B builds of the library (tools)
 
 if not os.path.exists(_SO):
     raise ImportError(f"{_SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
