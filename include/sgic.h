@@ -225,6 +225,18 @@ int sgic_gemm_split3_f32(const float *d_A, int lda, int a_seg, int a_seg_stride,
                          const uint16_t *d_Wplanes, const float *d_bias, const float *d_R, int ldr, float *d_C, int ldc,
                          uint16_t *d_Cplanes, int M, int N, int K, int act, int c_seg, int c_seg_stride,
                          const sgic_launch_opts *opts, sgic_stream_t stream);
+/* sgic_conv3x3_f32 as an implicit split GEMM: d_in_planes = bf16x3 planes [3][B (H+2) (W+2)][Cin] of the zero-halo NHWC
+ * input (sgic_split3_f32 over the halo buffer's rows), d_Wplanes = planes [3][Cout][9 Cin].  Cin % 32 == 0. */
+int sgic_conv3x3_split3_f32(const uint16_t *d_in_planes, const uint16_t *d_Wplanes, const float *d_bias, const float *d_R,
+                            int ldr, float *d_out, int ldc, int B, int H, int W, int Cin, int Cout, int act,
+                            const sgic_launch_opts *opts, sgic_stream_t stream);
+/* sgic_groupnorm_nhwc / sgic_halo_copy writing the interior of a zero-halo bf16x3 planes buffer
+ * [3][B (H+2) (W+2)][C] -- the input of sgic_conv3x3_split3_f32 -- directly (no fp32 halo buffer, no split pass). */
+int sgic_groupnorm_nhwc_split3(const float *d_x, const float *d_gamma, const float *d_beta, int B, int H, int W, int C,
+                               int groups, float eps, int swish, double *d_ws, float *d_stats, uint16_t *d_halo_planes,
+                               sgic_stream_t stream);
+int sgic_halo_copy_split3(const float *d_in, int B, int H, int W, int C, int upsample2x, int tile16, uint16_t *d_halo_planes,
+                          sgic_stream_t stream);
 /* sgic_attention_f32 with the output written as bf16x3 planes [3][rows][nheads*64] (rows = the row space of d_rowmap,
  * >= nseq*L): the A operand of the out-projection when that runs as a split GEMM. */
 int sgic_attention_split3_f32(const float *d_q, int ldq, const float *d_k, int ldk, const float *d_v, int ldv,

@@ -5,6 +5,7 @@
 // Reference: taming/modules/diffusionmodules/model.py:34-53,78-192,506-537; models/codec_sq_fixbpp.py:203-207,
 // 248-300,658-669,886-892.
 #include "common.h"
+#include "split3.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -99,7 +100,7 @@ __global__ void gn_finalize_kernel(const double *__restrict__ part, int B, int H
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__ x, const float *__restrict__ stats,
                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
                                                        int B, int H, int W, int C, int G, int swish, int halo,
-                                                       float *__restrict__ y) {
+                                                       float *__restrict__ y, unsigned short *__restrict__ planes) {
   const int C4 = C >> 2, cpg = C / G;
   const int row = blockIdx.x;            // b*H + yy
   const int b = row / H, yy = row - b * H;
@@ -123,14 +124,39 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
       if (swish) r = r / (1.0f + __expf(-r));  // x * sigmoid(x)
       o[e] = r;
     }
-    reinterpret_cast<f32x4 *>(yr + (long)xx * C)[c4] = o;
+    if (planes) {   // halo output as bf16x3 planes [3][B (H+2) (W+2)][C]: the operand of an implicit split-GEMM convolution
+      const long prow = ((long)b * (H + 2) + yy + 1) * (W + 2) + 1 + xx;
+      s3_store4(planes, (long)B * (H + 2) * (W + 2) * C, (size_t)prow * C + c4 * 4, o);
+    } else {
+      reinterpret_cast<f32x4 *>(yr + (long)xx * C)[c4] = o;
+    }
   }
 }
+
+static int groupnorm_any(const float *d_x, const float *d_gamma, const float *d_beta, int B, int H, int W, int C, int groups,
+                         float eps, int swish, int halo_out, double *d_ws, float *d_stats, float *d_y, unsigned short *d_planes,
+                         sgic_stream_t stream);
 
 extern "C" int sgic_groupnorm_nhwc(const float *d_x, const float *d_gamma, const float *d_beta, int B, int H, int W, int C,
                                    int groups, float eps, int swish, int halo_out, double *d_ws, float *d_stats,
                                    float *d_y, sgic_stream_t stream) {
-  SGIC_REQUIRE(d_x && d_gamma && d_beta && d_ws && d_stats && d_y && B > 0 && H > 0 && W > 0, "args");
+  SGIC_REQUIRE(d_y, "y");
+  return groupnorm_any(d_x, d_gamma, d_beta, B, H, W, C, groups, eps, swish, halo_out, d_ws, d_stats, d_y, nullptr, stream);
+}
+
+// GroupNorm (+swish) whose output feeds a 3x3 convolution run as an implicit split GEMM (sgic_conv3x3_split3_f32): the
+// interior of the zero-halo planes buffer [3][B (H+2) (W+2)][C] is written directly (its border must already be zero)
+extern "C" int sgic_groupnorm_nhwc_split3(const float *d_x, const float *d_gamma, const float *d_beta, int B, int H, int W, int C,
+                                          int groups, float eps, int swish, double *d_ws, float *d_stats,
+                                          uint16_t *d_halo_planes, sgic_stream_t stream) {
+  SGIC_REQUIRE(d_halo_planes && ((uintptr_t)d_halo_planes & 7) == 0, "planes");
+  return groupnorm_any(d_x, d_gamma, d_beta, B, H, W, C, groups, eps, swish, 1, d_ws, d_stats, nullptr, d_halo_planes, stream);
+}
+
+static int groupnorm_any(const float *d_x, const float *d_gamma, const float *d_beta, int B, int H, int W, int C, int groups,
+                         float eps, int swish, int halo_out, double *d_ws, float *d_stats, float *d_y, unsigned short *d_planes,
+                         sgic_stream_t stream) {
+  SGIC_REQUIRE(d_x && d_gamma && d_beta && d_ws && d_stats && (d_y || d_planes) && B > 0 && H > 0 && W > 0, "args");
   SGIC_REQUIRE(C % 4 == 0 && C % groups == 0 && (C / 4) <= 256 && 256 % (C / 4) == 0, "C must be 4*2^k <= 1024 and a multiple of groups");
   const int HW = H * W;
   int S = HW / 1024;
@@ -142,7 +168,7 @@ extern "C" int sgic_groupnorm_nhwc(const float *d_x, const float *d_gamma, const
     const int xstep = 256 / (C / 4);
     int chunks = (W + xstep * 8 - 1) / (xstep * 8);   // ~8 positions per thread
     chunks = chunks < 1 ? 1 : chunks;
-    gn_apply_kernel<<<dim3(B * H, chunks), 256, 0, st>>>(d_x, d_stats, d_gamma, d_beta, B, H, W, C, groups, swish, halo_out, d_y);
+    gn_apply_kernel<<<dim3(B * H, chunks), 256, 0, st>>>(d_x, d_stats, d_gamma, d_beta, B, H, W, C, groups, swish, halo_out, d_y, d_planes);
   }
   return sgic::check_launch("groupnorm");
 }
@@ -152,7 +178,7 @@ extern "C" int sgic_groupnorm_nhwc(const float *d_x, const float *d_gamma, const
 // upsampled (Upsample, model.py:49-53).  The halo itself is zeroed once by the caller (memset).
 // ------------------------------------------------------------------------------------------------
 __global__ void halo_copy_kernel(const float *__restrict__ in, int B, int H, int W, int C, int up, int tile16,
-                                 float *__restrict__ out) {
+                                 float *__restrict__ out, unsigned short *__restrict__ planes) {
   const int C4 = C >> 2, OH = H << up, OW = W << up;
   const long total = (long)B * OH * OW * C4;
   GRID_STRIDE(i, total) {
@@ -165,7 +191,9 @@ __global__ void halo_copy_kernel(const float *__restrict__ in, int B, int H, int
     const int sy = oy >> up, sx = ox >> up;
     const long irow = tile16 ? tm16_row(b, sy, sx, H, W) : ((long)b * H + sy) * W + sx;
     const f32x4 v = reinterpret_cast<const f32x4 *>(in + irow * C)[c4];
-    reinterpret_cast<f32x4 *>(out + (((long)b * (OH + 2) + oy + 1) * (OW + 2) + ox + 1) * C)[c4] = v;
+    const long prow = ((long)b * (OH + 2) + oy + 1) * (OW + 2) + ox + 1;
+    if (planes) s3_store4(planes, (long)B * (OH + 2) * (OW + 2) * C, (size_t)prow * C + c4 * 4, v);
+    else reinterpret_cast<f32x4 *>(out + prow * C)[c4] = v;
   }
 }
 
@@ -175,7 +203,19 @@ extern "C" int sgic_halo_copy(const float *d_in, int B, int H, int W, int C, int
   SGIC_REQUIRE(!tile16 || (H % 16 == 0 && W % 16 == 0), "tile-major input needs H,W multiples of 16");
   const int up = upsample2x ? 1 : 0;
   halo_copy_kernel<<<ew_grid((long)B * (H << up) * (W << up) * C / 4), 256, 0, to_stream(stream)>>>(d_in, B, H, W, C, up,
-                                                                                                   tile16, d_out);
+                                                                                                   tile16, d_out, nullptr);
+  return sgic::check_launch("halo_copy_kernel");
+}
+
+// the same copy into the interior of a zero-halo bf16x3 planes buffer [3][B (OH+2) (OW+2)][C] (operand of
+// sgic_conv3x3_split3_f32)
+extern "C" int sgic_halo_copy_split3(const float *d_in, int B, int H, int W, int C, int upsample2x, int tile16,
+                                     uint16_t *d_halo_planes, sgic_stream_t stream) {
+  SGIC_REQUIRE(d_in && d_halo_planes && B > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && ((uintptr_t)d_halo_planes & 7) == 0, "args");
+  SGIC_REQUIRE(!tile16 || (H % 16 == 0 && W % 16 == 0), "tile-major input needs H,W multiples of 16");
+  const int up = upsample2x ? 1 : 0;
+  halo_copy_kernel<<<ew_grid((long)B * (H << up) * (W << up) * C / 4), 256, 0, to_stream(stream)>>>(d_in, B, H, W, C, up,
+                                                                                                   tile16, nullptr, d_halo_planes);
   return sgic::check_launch("halo_copy_kernel");
 }
 

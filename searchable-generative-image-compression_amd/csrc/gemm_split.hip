@@ -74,6 +74,9 @@ struct S3Args {
   unsigned short *Cp;            // optional: the result as bf16x3 planes [3][M][N] (the next GEMM's A operand) instead of C
   long c_plane;                  // elements between the planes of Cp
   int vec_epilogue;              // C / R / bias rows are float4-addressable
+  // implicit-GEMM 3x3 convolution (stride 1, pad 1), as gemm.hip: A = planes of a zero-halo NHWC buffer [B, H+2, W+2, C], logical
+  // row m = output pixel (b,y,x), K = 9 C ordered (ky,kx,c); conv_C == 0 disables.  C % 32 == 0: a K slice never straddles a tap
+  int conv_C, conv_H, conv_W;
 };
 
 // Tile = (16 BM WAVES_M) x (16 BN WAVES_N); every wave owns BM x BN blocks of 16 x 16 on v_mfma_f32_16x16x32_bf16 (one MFMA =
@@ -128,17 +131,30 @@ void gemm_split3_kernel(S3Args g) {
   const int sw = srow * 64 + ((sslot ^ swz(srow)) * 16);
   const unsigned short *aptr[CA], *wptr[CW];
 #pragma unroll
-  for (int i = 0; i < CA; i++) aptr[i] = g.A + (size_t)min(m0 + srow + i * (NT / 4), g.M - 1) * g.K + sslot * 8;
+  for (int i = 0; i < CA; i++) {
+    const int am = min(m0 + srow + i * (NT / 4), g.M - 1);
+    if (g.conv_C) {   // top-left pixel of the 3x3 patch in the halo buffer
+      const int hw = g.conv_H * g.conv_W, b = am / hw, r = am - b * hw, y = r / g.conv_W, x = r - y * g.conv_W;
+      aptr[i] = g.A + (((size_t)b * (g.conv_H + 2) + y) * (g.conv_W + 2) + x) * g.conv_C + sslot * 8;
+    } else {
+      aptr[i] = g.A + (size_t)am * g.K + sslot * 8;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < CW; i++) wptr[i] = g.W + (size_t)min(n0 + srow + i * (NT / 4), g.N - 1) * g.K + sslot * 8;
   const bool a_on = CA * NT == TM * 4 || srow < TM, w_on = CW * NT == TN * 4 || srow < TN;   // tiles smaller than a pass
   u32x4 ra[NS][3][CA], rw[NS][3][CW];
   auto issue = [&](int k0, auto set_c) {
     constexpr int S = decltype(set_c)::value;
+    int ka = k0;
+    if (g.conv_C) {   // wave-uniform: the tap this K slice belongs to
+      const int tap = k0 / g.conv_C, c0 = k0 - tap * g.conv_C, ky = tap / 3, kx = tap - 3 * ky;
+      ka = (ky * (g.conv_W + 2) + kx) * g.conv_C + c0;
+    }
 #pragma unroll
     for (int p = 0; p < 3; p++) {
 #pragma unroll
-      for (int i = 0; i < CA; i++) ra[S][p][i] = *reinterpret_cast<const u32x4 *>(aptr[i] + p * g.a_plane + k0);
+      for (int i = 0; i < CA; i++) ra[S][p][i] = *reinterpret_cast<const u32x4 *>(aptr[i] + p * g.a_plane + ka);
 #pragma unroll
       for (int i = 0; i < CW; i++) rw[S][p][i] = *reinterpret_cast<const u32x4 *>(wptr[i] + p * g.w_plane + k0);
     }
@@ -428,6 +444,43 @@ static int s3_mode(const S3Args &g, int mode, hipStream_t st, hipEvent_t e0, hip
   }
 }
 
+static int s3_dispatch(const S3Args &g, int ldc, int ldr, int c_seg, const sgic_launch_opts *opts, hipStream_t st) {
+  const int M = g.M, N = g.N, K = g.K;
+  int mode = opts ? opts->tile_mode : 0;
+  SGIC_REQUIRE(mode >= 0 && mode <= SGIC_SPLIT3_TILE_MODES, "tile_mode");
+  if (!mode) {
+    // the largest tile whose grid still fills the 256 CUs ~twice over; launches that cannot fill the chip take the small tiles
+    const long t256 = (long)((M + 127) / 128) * ((N + 255) / 256), t128 = (long)((M + 127) / 128) * ((N + 127) / 128),
+               t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
+    mode = t256 >= 512 ? 1 : (t128 >= 384 ? 2 : (t64 >= 256 ? 3 : 4));
+  }
+  const auto *evp = prof_next(opts);
+  hipEvent_t e0 = evp ? evp->first : nullptr, e1 = evp ? evp->second : nullptr;
+  if (mode >= 6) {
+    // modes 6 / 7 = modes 1 / 2 for the rows that fill WHOLE rounds of the 256 CUs + the 64x128 two-per-CU tiles for the rest,
+    // as two launches (the first ends on a full round, so nothing idles at the seam): a last round of big tiles that covers a
+    // fraction of the chip costs a whole tile time, the small tiles finish it in about half.  One profiler record spans both.
+    const int big = mode - 5, TM = 128, TN = big == 1 ? 256 : 128;
+    const long tiles_n = (N + TN - 1) / TN, tiles_m = (M + TM - 1) / TM;
+    const long m_full = (tiles_m * tiles_n / 256) * 256 / tiles_n;   // m-tiles inside whole rounds
+    const long m_split = m_full * TM;
+    if (m_full > 0 && m_split < M && c_seg == 0 && !g.conv_C) {
+      S3Args g1 = g, g2 = g;
+      g1.M = (int)m_split;
+      g2.M = M - (int)m_split;
+      g2.A += m_split * K;
+      if (g2.C) g2.C += m_split * ldc;
+      if (g2.R) g2.R += m_split * ldr;
+      if (g2.Cp) g2.Cp += m_split * N;
+      int rc = s3_mode(g1, big, st, e0, nullptr);
+      if (rc) return rc;
+      return s3_mode(g2, 5, st, nullptr, e1);
+    }
+    mode = big;
+  }
+  return s3_mode(g, mode, st, e0, e1);
+}
+
 // C[M,N] = act(A . W^T + bias) + R with both operands as bf16x3 planes (see the header of this file).
 //   d_A != NULL: A (fp32, lda, row map a_seg) is split into d_Aplanes (caller's workspace, 3*M*K bf16) first;
 //   d_A == NULL: d_Aplanes already holds the planes (written by sgic_split3_f32 or a producing kernel).
@@ -453,39 +506,25 @@ extern "C" int sgic_gemm_split3_f32(const float *d_A, int lda, int a_seg, int a_
   const int vec = (N % 4 == 0) && (!d_bias || ((uintptr_t)d_bias & 15) == 0) && (!d_R || ((ldr % 4 == 0) && ((uintptr_t)d_R & 15) == 0)) &&
                   (d_Cplanes ? ((uintptr_t)d_Cplanes & 7) == 0 : ((ldc % 4 == 0) && ((uintptr_t)d_C & 15) == 0));
   SGIC_REQUIRE(!d_Cplanes || (vec && c_seg == 0), "planes output needs float4-addressable operands and no row map");
-  S3Args g{d_Aplanes, d_Wplanes, d_bias, d_R, d_C, M, N, K, ldr, ldc, act, c_seg, c_seg_stride, (long)M * K, (long)N * K, d_Cplanes, (long)M * N, vec};
-  int mode = opts ? opts->tile_mode : 0;
-  SGIC_REQUIRE(mode >= 0 && mode <= SGIC_SPLIT3_TILE_MODES, "tile_mode");
-  if (!mode) {
-    // the largest tile whose grid still fills the 256 CUs ~twice over; launches that cannot fill the chip take the small tiles
-    const long t256 = (long)((M + 127) / 128) * ((N + 255) / 256), t128 = (long)((M + 127) / 128) * ((N + 127) / 128),
-               t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
-    mode = t256 >= 512 ? 1 : (t128 >= 384 ? 2 : (t64 >= 256 ? 3 : 4));
-  }
-  hipStream_t st = to_stream(stream);
-  const auto *evp = prof_next(opts);
-  hipEvent_t e0 = evp ? evp->first : nullptr, e1 = evp ? evp->second : nullptr;
-  if (mode >= 6) {
-    // modes 6 / 7 = modes 1 / 2 for the rows that fill WHOLE rounds of the 256 CUs + the 64x128 two-per-CU tiles for the rest,
-    // as two launches (the first ends on a full round, so nothing idles at the seam): a last round of big tiles that covers a
-    // fraction of the chip costs a whole tile time, the small tiles finish it in about half.  One profiler record spans both.
-    const int big = mode - 5, TM = 128, TN = big == 1 ? 256 : 128;
-    const long tiles_n = (N + TN - 1) / TN, tiles_m = (M + TM - 1) / TM;
-    const long m_full = (tiles_m * tiles_n / 256) * 256 / tiles_n;   // m-tiles inside whole rounds
-    const long m_split = m_full * TM;
-    if (m_full > 0 && m_split < M && c_seg == 0) {
-      S3Args g1 = g, g2 = g;
-      g1.M = (int)m_split;
-      g2.M = M - (int)m_split;
-      g2.A += m_split * K;
-      if (g2.C) g2.C += m_split * ldc;
-      if (g2.R) g2.R += m_split * ldr;
-      if (g2.Cp) g2.Cp += m_split * N;
-      int rc = s3_mode(g1, big, st, e0, nullptr);
-      if (rc) return rc;
-      return s3_mode(g2, 5, st, nullptr, e1);
-    }
-    mode = big;
-  }
-  return s3_mode(g, mode, st, e0, e1);
+  S3Args g{d_Aplanes, d_Wplanes, d_bias, d_R, d_C, M, N, K, ldr, ldc, act, c_seg, c_seg_stride, (long)M * K, (long)N * K, d_Cplanes, (long)M * N, vec, 0, 0, 0};
+  return s3_dispatch(g, ldc, ldr, c_seg, opts, to_stream(stream));
+}
+
+// 3x3 stride-1 pad-1 convolution as an implicit split GEMM (taming ResnetBlock / Upsample / conv_in, model.py:38-137,436-537;
+// the call sites of sgic_conv3x3_f32): d_in_planes = bf16x3 planes [3][halo_rows][Cin] of the zero-halo NHWC input
+// (halo_rows = B (H+2) (W+2)), d_Wplanes = planes [3][Cout][9 Cin] of the (ky,kx,cin)-ordered weight.  Cin % 32 == 0.
+extern "C" int sgic_conv3x3_split3_f32(const uint16_t *d_in_planes, const uint16_t *d_Wplanes, const float *d_bias,
+                                       const float *d_R, int ldr, float *d_out, int ldc, int B, int H, int W, int Cin, int Cout,
+                                       int act, const sgic_launch_opts *opts, sgic_stream_t stream) {
+  const long Ml = (long)B * H * W, halo_rows = (long)B * (H + 2) * (W + 2);
+  SGIC_REQUIRE(d_in_planes && d_Wplanes && d_out && B > 0 && H > 0 && W > 0 && Cout > 0, "null/empty");
+  SGIC_REQUIRE(Ml < (1l << 31), "too many pixels");
+  SGIC_REQUIRE(Cin > 0 && Cin % 32 == 0, "implicit-GEMM conv needs Cin % 32 == 0");
+  SGIC_REQUIRE(((uintptr_t)d_in_planes & 15) == 0 && ((uintptr_t)d_Wplanes & 15) == 0, "planes must be 16-byte aligned");
+  SGIC_REQUIRE(ldc >= Cout && (!d_R || ldr >= Cout) && act >= 0 && act <= ACT_LRELU, "leading dimensions / activation");
+  const int M = (int)Ml, N = Cout, K = 9 * Cin;
+  const int vec = (N % 4 == 0) && (!d_bias || ((uintptr_t)d_bias & 15) == 0) && (!d_R || ((ldr % 4 == 0) && ((uintptr_t)d_R & 15) == 0)) &&
+                  (ldc % 4 == 0) && ((uintptr_t)d_out & 15) == 0;
+  S3Args g{d_in_planes, d_Wplanes, d_bias, d_R, d_out, M, N, K, ldr, ldc, act, 0, 0, halo_rows * Cin, (long)N * K, nullptr, 0, vec, Cin, H, W};
+  return s3_dispatch(g, ldc, ldr, 0, opts, to_stream(stream));
 }

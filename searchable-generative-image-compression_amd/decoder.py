@@ -152,9 +152,11 @@ class VqganDecoderHIP:
 
     @staticmethod
     def _res(x, w: _ResW, B, H, W):
-        h = ops.groupnorm(x, w.n1w, w.n1b, B, H, W, swish=True, halo=True)
+        # to_conv = (Cout, has_residual) of the consuming 3x3 conv: under the split arithmetic the halo buffer is written directly
+        # as that conv's operand planes
+        h = ops.groupnorm(x, w.n1w, w.n1b, B, H, W, swish=True, halo=True, to_conv=(w.cout, False))
         h = ops.conv3x3(h, w.c1w, w.c1b, B, H, W, w.cin, w.cout)
-        h = ops.groupnorm(h, w.n2w, w.n2b, B, H, W, swish=True, halo=True)
+        h = ops.groupnorm(h, w.n2w, w.n2b, B, H, W, swish=True, halo=True, to_conv=(w.cout, True))
         sc = ops.gemm(x, w.sw, w.sb) if w.sw is not None else x
         return ops.conv3x3(h, w.c2w, w.c2b, B, H, W, w.cout, w.cout, residual=sc)
 
@@ -178,7 +180,7 @@ class VqganDecoderHIP:
         """latent [(B*H*W), embed_dim] (tile-major rows if tile16) -> x_hat (B,3,16H,16W) clamped"""
         cfg = self.cfg
         z = ops.gemm(latent, self.pq_w, self.pq_b)                                    # post_quant_conv 1x1
-        zh = ops.halo_copy(z, B, H, W, cfg.vq_z_channels, upsample=False, tile16=tile16)
+        zh = ops.halo_copy(z, B, H, W, cfg.vq_z_channels, upsample=False, tile16=tile16, to_conv=(self.c0, False))
         h = ops.conv3x3(zh, self.ci_w, self.ci_b, B, H, W, cfg.vq_z_channels, self.c0)
         h = self._res(h, self.mid1, B, H, W)
         h = self._attn(h, self.mida, B, H, W)
@@ -190,7 +192,7 @@ class VqganDecoderHIP:
                     h = self._attn(h, a, B, H, W)
             if upw is not None:
                 c = h.shape[1]
-                hu = ops.halo_copy(h, B, H, W, c, upsample=True, tile16=False)
+                hu = ops.halo_copy(h, B, H, W, c, upsample=True, tile16=False, to_conv=(c, False))
                 H, W = 2 * H, 2 * W
                 h = ops.conv3x3(hu, upw[0], upw[1], B, H, W, c, c)
         hn = ops.groupnorm(h, self.no_w, self.no_b, B, H, W, swish=True, halo=True)

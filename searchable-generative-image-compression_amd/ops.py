@@ -159,7 +159,7 @@ def tile_of(key, dev=None):
     """launch mode in use for a profile-record shape key (bench.py's by_shape table)"""
     if key and key[0] == "batched":
         return 0
-    if key and key[0] == "conv3x3":
+    if key and key[0] in ("conv3x3", "conv3"):
         return _TILE.get(key)
     M, N, K, res, act = key[:5]
     kind = "gemm3" if len(key) > 5 and key[5] == "s3" else "gemm"
@@ -251,7 +251,7 @@ _CTX = {}
 
 def M_big(key):
     """in-context re-timing synchronises the stream once per sample: only worth it for launches of >= ~50 us"""
-    if key[0] == "conv3x3":
+    if key[0] in ("conv3x3", "conv3"):
         return True
     return 2.0 * key[1] * key[2] * key[3] >= 5e9
 
@@ -706,16 +706,72 @@ def gemm_batched(a, lda, sa, w, ldw, sw, out, ldc, sc, M, N, K, batch, bias=None
     return out
 
 
-def conv3x3(x_halo, w, bias, B, H, W, Cin, Cout, residual=None, act=ACT_NONE, out=None, tile=None):
+class HaloPlanes:
+    """the zero-halo input of a 3x3 convolution held as bf16x3 planes [3, B (H+2) (W+2), C] (int16 bit patterns), written
+    directly by groupnorm / halo_copy when the convolution runs as an implicit split GEMM"""
+    __slots__ = ("t", "B", "H", "W", "C")
+
+    def __init__(self, t, B, H, W, C):
+        self.t, self.B, self.H, self.W, self.C = t, B, H, W, C
+
+
+_HALO3 = {}
+
+
+def halo_planes_buffer(dev, B, H, W, C):
+    """cached like halo_buffer: producers only write the interior, the border planes stay zero"""
+    key = (str(dev), B, H, W, C)
+    if key not in _HALO3:
+        _HALO3[key] = HaloPlanes(torch.zeros(3 * B * (H + 2) * (W + 2) * C, device=dev, dtype=torch.int16), B, H, W, C)
+    return _HALO3[key]
+
+
+def conv_planes_ok(Cin, Cout, residual=False, precision=None):
+    """does conv3x3 with these channels run as an implicit split GEMM (so its producer may write halo planes directly)?"""
+    return (precision or PRECISION) == "split3" and Cin % 32 == 0 and not (Cout == 3 and Cin == 128 and not residual)
+
+
+def conv3x3(x_halo, w, bias, B, H, W, Cin, Cout, residual=None, act=ACT_NONE, out=None, tile=None, precision=None):
     """x_halo: zero-halo NHWC buffer (B, H+2, W+2, Cin); w: (Cout, 9*Cin) in (ky,kx,cin) order -> (B*H*W, Cout)"""
-    assert x_halo.is_contiguous() and x_halo.numel() == B * (H + 2) * (W + 2) * Cin
+    hp = x_halo if isinstance(x_halo, HaloPlanes) else None
+    if hp is not None:
+        assert (hp.B, hp.H, hp.W, hp.C) == (B, H, W, Cin) and conv_planes_ok(Cin, Cout, residual is not None, precision)
+        dev = hp.t.device
+    else:
+        assert x_halo.is_contiguous() and x_halo.numel() == B * (H + 2) * (W + 2) * Cin
+        dev = x_halo.device
     assert w.shape == (Cout, 9 * Cin) and w.is_contiguous()
     if out is None:
-        out = torch.empty(B * H * W, Cout, device=x_halo.device, dtype=torch.float32)
+        out = torch.empty(B * H * W, Cout, device=dev, dtype=torch.float32)
     out, ldc = _rows(out)
     ldr = 0
     if residual is not None:
         residual, ldr = _rows(residual)
+
+    if conv_planes_ok(Cin, Cout, residual is not None, precision):
+        # implicit split GEMM: the weight's planes are cached; the halo planes come from the producer, or from one split pass
+        # over the fp32 halo buffer's rows
+        rows = B * (H + 2) * (W + 2)
+        wp = weight_planes(w, 9 * Cin)
+        if hp is not None:
+            ws = hp.t
+        else:
+            ws = _a3_workspace(dev, 3 * rows * Cin)
+            call("sgic_split3_f32", _p(x_halo), Cin, rows, Cin, 0, 0, _p(ws))
+
+        def launch3(mode, prof=None):
+            call("sgic_conv3x3_split3_f32", _p(ws), _p(wp), _p(bias), _p(residual), ldr, _p(out), ldc, B, H, W, Cin, Cout, act,
+                 _opts(tile=mode, prof=prof))
+
+        if tile is not None:
+            launch3(tile)
+        else:
+            key = ("conv3", B * H * W, H, W, Cin, Cout, int(residual is not None), act)
+            if _pick_and_launch(key, launch3, B * H * W * Cout >= (1 << 20), modes=(1, 2, 3, 5)):
+                return out
+        if PROFILE is not None:
+            PROFILE.append((2.0 * B * H * W * Cout * 9 * Cin, (B * H * W, Cout, 9 * Cin, residual is not None, act, "s3")))
+        return out
 
     def launch(mode, prof=None):
         call("sgic_conv3x3_f32", _p(x_halo), _p(w), _p(bias), _p(residual), ldr, _p(out), ldc, B, H, W, Cin, Cout, act,
@@ -736,7 +792,7 @@ def conv3x3(x_halo, w, bias, B, H, W, Cin, Cout, residual=None, act=ACT_NONE, ou
 _GN_WS = {}
 
 
-def groupnorm(x, gamma, beta, B, H, W, swish=True, halo=False, groups=32, eps=1e-6, out=None):
+def groupnorm(x, gamma, beta, B, H, W, swish=True, halo=False, groups=32, eps=1e-6, out=None, to_conv=None):
     """x (B*H*W, C) plain NHWC -> normalised (+swish); halo=True writes the interior of a (B,H+2,W+2,C) buffer
     whose border must already be zero (pass `out`, or a fresh zero buffer is allocated)."""
     x, ldx = _rows(x)
@@ -748,6 +804,12 @@ def groupnorm(x, gamma, beta, B, H, W, swish=True, halo=False, groups=32, eps=1e
         _GN_WS[key] = (torch.empty(B * 64 * C * 2, dtype=torch.float64, device=dev),
                        torch.empty(B * groups * 2, dtype=torch.float32, device=dev))
     ws, stats = _GN_WS[key]
+    if halo and to_conv is not None and conv_planes_ok(C, to_conv[0], to_conv[1]):
+        # to_conv = (Cout, has_residual) of the 3x3 convolution that consumes this halo buffer: written as its operand planes
+        hp = halo_planes_buffer(dev, B, H, W, C)
+        call("sgic_groupnorm_nhwc_split3", _p(x), _p(gamma), _p(beta), B, H, W, C, groups, float(eps), int(swish), _p(ws), _p(stats),
+             _p(hp.t))
+        return hp
     if out is None:
         out = halo_buffer(dev, B, H, W, C) if halo else torch.empty(B * H * W, C, device=dev)
     call("sgic_groupnorm_nhwc", _p(x), _p(gamma), _p(beta), B, H, W, C, groups, float(eps), int(swish), int(halo), _p(ws),
@@ -768,8 +830,12 @@ def halo_buffer(dev, B, H, W, C):
     return _HALO[key]
 
 
-def halo_copy(x, B, H, W, C, upsample=False, tile16=False, out=None):
+def halo_copy(x, B, H, W, C, upsample=False, tile16=False, out=None, to_conv=None):
     s = 2 if upsample else 1
+    if to_conv is not None and conv_planes_ok(C, to_conv[0], to_conv[1]):
+        hp = halo_planes_buffer(x.device, B, H * s, W * s, C)
+        call("sgic_halo_copy_split3", _p(x), B, H, W, C, int(upsample), int(tile16), _p(hp.t))
+        return hp
     if out is None:
         out = halo_buffer(x.device, B, H * s, W * s, C)
     call("sgic_halo_copy", _p(x), B, H, W, C, int(upsample), int(tile16), _p(out))

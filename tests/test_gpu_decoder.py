@@ -123,8 +123,9 @@ def test_full_roundtrip_compress_decompress(codec):
 @pytest.mark.parametrize("B,H,W,Cin,Cout,res", [(2, 24, 40, 128, 3, False),      # thin VALU kernel (taming conv_out 128 -> 3)
                                                   (2, 24, 40, 64, 128, True),      # implicit-GEMM path with residual
                                                   (1, 16, 16, 128, 4, False)])     # Cout = 4 stays on the GEMM path
-def test_conv3x3_vs_torch(B, H, W, Cin, Cout, res):
-    """sgic_conv3x3_f32 (taming Conv2d 3x3 stride 1 pad 1, model.py:38-137,531-537) vs F.conv2d in fp64.
+@pytest.mark.parametrize("precision", ["f32", "split3"])
+def test_conv3x3_vs_torch(B, H, W, Cin, Cout, res, precision):
+    """sgic_conv3x3_f32 / sgic_conv3x3_split3_f32 (taming Conv2d 3x3 stride 1 pad 1, model.py:38-137,531-537) vs F.conv2d in fp64.
     Tolerance: 2e-5 * max|ref| (fp32 accumulation over K = 9*Cin <= 1152 terms)."""
     import sgic_amd  # noqa
     from sgic_amd import ops
@@ -142,8 +143,13 @@ def test_conv3x3_vs_torch(B, H, W, Cin, Cout, res):
     ld = 4 if Cout == 3 else Cout
     out = torch.zeros(B * H * W, ld, device="cuda:0")
     rr = r.permute(0, 2, 3, 1).reshape(B * H * W, Cout).contiguous().cuda() if res else None
-    ops.conv3x3(halo, wk, b.cuda(), B, H, W, Cin, Cout, residual=rr, out=out[:, :Cout])
+    ops.conv3x3(halo, wk, b.cuda(), B, H, W, Cin, Cout, residual=rr, out=out[:, :Cout], precision=precision)
     got = out[:, :Cout].reshape(B, H, W, Cout).permute(0, 3, 1, 2).cpu().double()
     assert float((got - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    if precision == "split3" and Cout != 3:      # every tile mode of the split kernel: bitwise the same convolution
+        for tile in (1, 2, 3, 5):
+            o2 = torch.zeros_like(out)
+            ops.conv3x3(halo, wk, b.cuda(), B, H, W, Cin, Cout, residual=rr, out=o2[:, :Cout], precision=precision, tile=tile)
+            assert torch.equal(o2, out), tile
     if ld > Cout:
         assert float(out[:, Cout:].abs().max()) == 0.0      # the padding column of the output buffer is untouched
