@@ -413,7 +413,7 @@ def main():
     dt_local = dt = time.perf_counter() - t0
     prof = ops.profile_end()      # [(flops, ms, shape key)] per launch of the timed region
     if rank == 0 and os.environ.get("SGIC_BENCH_SHAPES"):   # launch-ordered shape list (tools/pmc_by_shape.py joins it with PMC rows)
-        json.dump([[list(k) if isinstance(k, tuple) else k, fl, ms] for fl, ms, k in prof], open(os.environ["SGIC_BENCH_SHAPES"], "w"))
+        json.dump([[list(k) if isinstance(k, tuple) else k, fl, ms, ops.tile_of(k, dev)] for fl, ms, k in prof], open(os.environ["SGIC_BENCH_SHAPES"], "w"))
     gather_ms = sum(a.elapsed_time(b) for a, b in gather_events)
     per_rank = [(dt_local, gather_ms)]
     if world > 1:

@@ -77,6 +77,7 @@ struct S3Args {
   // implicit-GEMM 3x3 convolution (stride 1, pad 1), as gemm.hip: A = planes of a zero-halo NHWC buffer [B, H+2, W+2, C], logical
   // row m = output pixel (b,y,x), K = 9 C ordered (ky,kx,c); conv_C == 0 disables.  C % 32 == 0: a K slice never straddles a tap
   int conv_C, conv_H, conv_W;
+  int m_base;                    // logical row of this launch's row 0 (second launch of the split modes 6 / 7): enters the C row map
 };
 
 // Tile = (16 BM WAVES_M) x (16 BN WAVES_N); every wave owns BM x BN blocks of 16 x 16 on v_mfma_f32_16x16x32_bf16 (one MFMA =
@@ -326,7 +327,7 @@ void gemm_split3_kernel(S3Args g) {
         for (int q = 0; q < EB; ++q) {
           const int rr = (b + q) * RPI + r0;
           cv[q] = *reinterpret_cast<const f32x4 *>(ep + rr * LDW + c4);
-          if constexpr (HASR) rv[q] = *reinterpret_cast<const f32x4 *>(g.R + (size_t)min(m0 + wm + rr, g.M - 1) * g.ldr + nc);
+          if constexpr (HASR) rv[q] = *reinterpret_cast<const f32x4 *>(g.R + (size_t)(min(m0 + wm + rr, g.M - 1) + g.m_base) * g.ldr + nc);
         }
 #pragma unroll
         for (int q = 0; q < EB; ++q) {
@@ -337,9 +338,10 @@ void gemm_split3_kernel(S3Args g) {
           if constexpr (HASR) v += rv[q];
           if (colok && m < g.M) {
             if constexpr (PLANES) {
-              s3_store4(g.Cp, g.c_plane, (size_t)m * g.N + n, v);
+              s3_store4(g.Cp, g.c_plane, (size_t)(m + g.m_base) * g.N + n, v);
             } else {
-              const size_t crow = g.c_seg ? (size_t)(m / g.c_seg) * g.c_seg_stride + (m % g.c_seg) : (size_t)m;
+              const int mm = m + g.m_base;
+              const size_t crow = g.c_seg ? (size_t)(mm / g.c_seg) * g.c_seg_stride + (mm % g.c_seg) : (size_t)mm;
               *reinterpret_cast<f32x4 *>(g.C + crow * g.ldc + n) = v;
             }
           }
@@ -375,12 +377,13 @@ void gemm_split3_kernel(S3Args g) {
       for (int i = 0; i < BM; i++) {
         const int m = m0 + wm + i * 16 + l16;
         if (m >= g.M) continue;
-        const size_t crow = g.c_seg ? (size_t)(m / g.c_seg) * g.c_seg_stride + (m % g.c_seg) : (size_t)m;
+        const int mm = m + g.m_base;
+        const size_t crow = g.c_seg ? (size_t)(mm / g.c_seg) * g.c_seg_stride + (mm % g.c_seg) : (size_t)mm;
 #pragma unroll
         for (int t = 0; t < 4; t++) {
           if (n + t < g.N) {
             float o = apply_act_c<ACT>(acc[i][j][t] + (g.bias ? g.bias[n + t] : 0.f));
-            if constexpr (HASR) o += g.R[(size_t)m * g.ldr + n + t];
+            if constexpr (HASR) o += g.R[(size_t)mm * g.ldr + n + t];
             g.C[crow * g.ldc + n + t] = o;
           }
         }
@@ -444,7 +447,7 @@ static int s3_mode(const S3Args &g, int mode, hipStream_t st, hipEvent_t e0, hip
   }
 }
 
-static int s3_dispatch(const S3Args &g, int ldc, int ldr, int c_seg, const sgic_launch_opts *opts, hipStream_t st) {
+static int s3_dispatch(const S3Args &g, const sgic_launch_opts *opts, hipStream_t st) {
   const int M = g.M, N = g.N, K = g.K;
   int mode = opts ? opts->tile_mode : 0;
   SGIC_REQUIRE(mode >= 0 && mode <= SGIC_SPLIT3_TILE_MODES, "tile_mode");
@@ -464,14 +467,12 @@ static int s3_dispatch(const S3Args &g, int ldc, int ldr, int c_seg, const sgic_
     const long tiles_n = (N + TN - 1) / TN, tiles_m = (M + TM - 1) / TM;
     const long m_full = (tiles_m * tiles_n / 256) * 256 / tiles_n;   // m-tiles inside whole rounds
     const long m_split = m_full * TM;
-    if (m_full > 0 && m_split < M && c_seg == 0 && !g.conv_C) {
+    if (m_full > 0 && m_split < M && !g.conv_C) {
       S3Args g1 = g, g2 = g;
       g1.M = (int)m_split;
       g2.M = M - (int)m_split;
-      g2.A += m_split * K;
-      if (g2.C) g2.C += m_split * ldc;
-      if (g2.R) g2.R += m_split * ldr;
-      if (g2.Cp) g2.Cp += m_split * N;
+      g2.A += m_split * K;          // the planes keep their stride (a_plane); C / R / Cp rows are addressed through m_base
+      g2.m_base = (int)m_split;
       int rc = s3_mode(g1, big, st, e0, nullptr);
       if (rc) return rc;
       return s3_mode(g2, 5, st, nullptr, e1);
@@ -506,8 +507,8 @@ extern "C" int sgic_gemm_split3_f32(const float *d_A, int lda, int a_seg, int a_
   const int vec = (N % 4 == 0) && (!d_bias || ((uintptr_t)d_bias & 15) == 0) && (!d_R || ((ldr % 4 == 0) && ((uintptr_t)d_R & 15) == 0)) &&
                   (d_Cplanes ? ((uintptr_t)d_Cplanes & 7) == 0 : ((ldc % 4 == 0) && ((uintptr_t)d_C & 15) == 0));
   SGIC_REQUIRE(!d_Cplanes || (vec && c_seg == 0), "planes output needs float4-addressable operands and no row map");
-  S3Args g{d_Aplanes, d_Wplanes, d_bias, d_R, d_C, M, N, K, ldr, ldc, act, c_seg, c_seg_stride, (long)M * K, (long)N * K, d_Cplanes, (long)M * N, vec, 0, 0, 0};
-  return s3_dispatch(g, ldc, ldr, c_seg, opts, to_stream(stream));
+  S3Args g{d_Aplanes, d_Wplanes, d_bias, d_R, d_C, M, N, K, ldr, ldc, act, c_seg, c_seg_stride, (long)M * K, (long)N * K, d_Cplanes, (long)M * N, vec, 0, 0, 0, 0};
+  return s3_dispatch(g, opts, to_stream(stream));
 }
 
 // 3x3 stride-1 pad-1 convolution as an implicit split GEMM (taming ResnetBlock / Upsample / conv_in, model.py:38-137,436-537;
@@ -525,6 +526,6 @@ extern "C" int sgic_conv3x3_split3_f32(const uint16_t *d_in_planes, const uint16
   const int M = (int)Ml, N = Cout, K = 9 * Cin;
   const int vec = (N % 4 == 0) && (!d_bias || ((uintptr_t)d_bias & 15) == 0) && (!d_R || ((ldr % 4 == 0) && ((uintptr_t)d_R & 15) == 0)) &&
                   (ldc % 4 == 0) && ((uintptr_t)d_out & 15) == 0;
-  S3Args g{d_in_planes, d_Wplanes, d_bias, d_R, d_out, M, N, K, ldr, ldc, act, 0, 0, halo_rows * Cin, (long)N * K, nullptr, 0, vec, Cin, H, W};
-  return s3_dispatch(g, ldc, ldr, 0, opts, to_stream(stream));
+  S3Args g{d_in_planes, d_Wplanes, d_bias, d_R, d_out, M, N, K, ldr, ldc, act, 0, 0, halo_rows * Cin, (long)N * K, nullptr, 0, vec, Cin, H, W, 0};
+  return s3_dispatch(g, opts, to_stream(stream));
 }

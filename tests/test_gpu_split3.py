@@ -180,3 +180,32 @@ def test_attention_planes_output(ops, L, nseq, heads):
         assert torch.equal(pl.t.view(3, nseq * L, D), ops.split3(ref))
     finally:
         ops.set_precision(old)
+
+
+def test_split_launch_modes_with_row_map_residual_and_planes(ops):
+    """modes 6 / 7 (whole rounds of big tiles + a tail launch): the tail addresses C / R / the planes through its row base"""
+    g = torch.Generator(device="cuda").manual_seed(31)
+    n, Lt, L, K, N = 4, 3000, 3500, 256, 768
+    M = n * Lt                                   # 94 m-tiles x 3 (or 6) n-tiles: a whole round + a tail at row 10880
+    a = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) * 0.1
+    bias = torch.randn(N, device="cuda", generator=g)
+    r = torch.randn(M, N, device="cuda", generator=g)
+    ref = {}
+    for tile in (1, 6, 7):
+        out = torch.zeros(n * L, N, device="cuda")
+        ops.gemm(a, w, bias, out=out, M=M, c_seg=(Lt, L), precision="split3", tile=tile)
+        y = ops.gemm(a, w, bias, residual=r, act=ops.ACT_SILU, precision="split3", tile=tile)
+        old = ops.PRECISION
+        ops.set_precision("split3")
+        try:
+            pl = ops.gemm(a, w, bias, residual=r, to_gemm=True, tile=tile)
+        finally:
+            ops.set_precision(old)
+        torch.cuda.synchronize()
+        ref[tile] = (out.clone(), y.clone(), pl.t.clone())
+    for tile in (6, 7):
+        assert all(torch.equal(p, q) for p, q in zip(ref[1], ref[tile])), tile
+    o3 = ref[1][0].reshape(n, L, N)
+    want = (a.double() @ w.double().T + bias.double()).reshape(n, Lt, N)
+    assert float((o3[:, :Lt].double() - want).abs().max()) < 1e-4 and float(o3[:, Lt:].abs().max()) == 0.0

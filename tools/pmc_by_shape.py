@@ -12,22 +12,51 @@ shapes = json.load(open(shapes_json))
 n = len(shapes)
 
 
+def is_s3(key):
+    return len(key) > 5 and key[5] == "s3"
+
+
+def dispatches(rec):
+    """kernel dispatches behind one profile record: the split GEMM's modes 6 / 7 are two launches when the grid has whole rounds
+    of the 256 CUs plus a tail (csrc/gemm_split.hip: s3_dispatch)"""
+    key, mode = rec[0], (rec[3] if len(rec) > 3 else None)
+    if not is_s3(key) or mode not in (6, 7):
+        return 1
+    M, N = key[0], key[1]
+    tn = 256 if mode == 6 else 128
+    tiles_n, tiles_m = (N + tn - 1) // tn, (M + 127) // 128
+    m_full = (tiles_m * tiles_n // 256) * 256 // tiles_n
+    return 2 if (m_full > 0 and m_full * 128 < M) else 1
+
+
+ndisp = [dispatches(r) for r in shapes]
+total_disp = sum(ndisp)
+s3_share = sum(1 for r in shapes if is_s3(r[0])) / max(1, n)
+
+
 def load(tag, counter):
     rows = []
     for f in glob.glob(f"{root}_{tag}/**/*counter_collection.csv", recursive=True):
         rows += [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and
-                 any(k in r["Kernel_Name"] for k in ("gemm_f32_kernel", "gemm_lat16_kernel", "conv3x3_thin"))]
+                 any(k in r["Kernel_Name"] for k in ("gemm_f32_kernel", "gemm_lat16_kernel", "conv3x3_thin", "gemm_split3_kernel"))]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    return [float(r["Counter_Value"]) for r in rows[-n:]]
+    vals = [float(r["Counter_Value"]) for r in rows[-total_disp:]]
+    out, i = [], 0
+    for d in ndisp:          # a record that is two launches: the counters of both
+        out.append(sum(vals[i:i + d]))
+        i += d
+    return out
 
 
 fetch, write = load("FETCH_SIZE", "FETCH_SIZE"), load("WRITE_SIZE", "WRITE_SIZE")
 busy, act = load("MFMA", "SQ_VALU_MFMA_BUSY_CYCLES"), load("MFMA", "GRBM_GUI_ACTIVE")
 assert len(fetch) == len(write) == len(busy) == n, (len(fetch), len(write), len(busy), n)
 agg = {}
-for i, (key, fl, ms) in enumerate(shapes):
+for i, rec in enumerate(shapes):
+    key, fl, ms = rec[0], rec[1], rec[2]
     k = tuple(key[:3]) if key[0] != "batched" else tuple(key[2:5])
-    a = agg.setdefault(k, dict(calls=0, fetch=0.0, write=0.0, busy=0.0, act=0.0, ms=0.0, flops=0.0, res=bool(key[3]) if key[0] != "batched" else False))
+    a = agg.setdefault(k, dict(calls=0, fetch=0.0, write=0.0, busy=0.0, act=0.0, ms=0.0, flops=0.0, res=bool(key[3]) if key[0] != "batched" else False,
+                               s3=is_s3(key)))
     a["calls"] += 1
     a["fetch"] += fetch[i]
     a["write"] += write[i]
@@ -37,9 +66,10 @@ for i, (key, fl, ms) in enumerate(shapes):
     a["flops"] += fl
 rows = []
 for (M, N, K), a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
-    algo = 4.0 * (M * K + N * K + M * N * (2 if a["res"] else 1))
+    # the split kernel reads its operands as three bf16 planes (6 B per element)
+    algo = (6.0 if a["s3"] else 4.0) * (M * K + N * K) + 4.0 * M * N * (2 if a["res"] else 1)
     cnt = (2 * a["fetch"] + a["write"]) * 1024 / a["calls"]
-    rows.append({"shape": [M, N, K], "calls": a["calls"], "algorithmic_MB": round(algo / 1e6, 1), "counter_MB": round(cnt / 1e6, 1),
+    rows.append({"shape": [M, N, K], "kernel": "split3" if a["s3"] else "f32", "calls": a["calls"], "algorithmic_MB": round(algo / 1e6, 1), "counter_MB": round(cnt / 1e6, 1),
                  "counter_over_algorithmic": round(cnt / algo, 2), "fetch_MB_x2": round(2 * a["fetch"] * 1024 / a["calls"] / 1e6, 1),
                  "write_MB": round(a["write"] * 1024 / a["calls"] / 1e6, 1),
                  "mfma_busy_fraction": round(a["busy"] / (a["act"] / 8 * 1024), 4) if a["act"] else None})
@@ -50,7 +80,7 @@ json.dump({"command": "tools/pmc_collect.sh (three rocprofv3 --pmc passes over b
 fs, ws, bs, ga = sum(fetch), sum(write), sum(busy), sum(act)
 summ = {"command": "rocprofv3 --pmc <counter set> --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-secondary --no-cpu-baseline "
                    "(three separate passes: FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE)",
-        "kernel": f"gemm_f32_kernel<...>: the {n} GEMM launches of the timed step", "launches": n,
+        "kernel": "gemm_split3_kernel" if s3_share > 0.5 else "gemm_f32_kernel", "what": f"the {n} GEMM-class launches of the timed step", "launches": n,
         "hbm_fetch_MB_per_launch_x2_corrected": round(2 * fs * 1024 / n / 1e6, 2), "hbm_write_MB_per_launch": round(ws * 1024 / n / 1e6, 2),
         "algorithmic_MB_per_launch": round(sum(r["algorithmic_MB"] * r["calls"] for r in rows) / n, 2),
         "SQ_VALU_MFMA_BUSY_CYCLES": bs, "GRBM_GUI_ACTIVE": ga, "mfma_busy_fraction": round(bs / (ga / 8 * 1024), 4) if ga else None}
