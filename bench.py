@@ -188,7 +188,7 @@ def rehearse_cpu(args, world, rank):
 
 
 # ------------------------------------------------------------------------------------------------ roofline helpers
-def by_shape_table(prof, ops, dev, top=10):
+def by_shape_table(prof, ops, dev, top=10, pmc_shapes="round2_pmc_gemm_by_shape.json"):
     """per-shape roofline of the GEMM launches from the per-launch event pairs of the timed region; `frac` is against the
     peak of the kernel the shape ran on (split GEMM: bf16 peak / 6; fp32 MFMA kernel: 157.3)"""
     agg = {}
@@ -200,7 +200,7 @@ def by_shape_table(prof, ops, dev, top=10):
     total_ms = sum(v[1] for v in agg.values()) or 1.0
     pmc = {}
     try:   # HBM-side counter bytes per launch and shape, from the committed rocprofv3 --pmc passes (tools/pmc_by_shape.py)
-        pmc = {tuple(r["shape"]): r for r in json.load(open(os.path.join(ROOT, "profiles", "round2_pmc_gemm_by_shape.json")))["shapes"]}
+        pmc = {tuple(r["shape"]): r for r in json.load(open(os.path.join(ROOT, "profiles", pmc_shapes)))["shapes"]}
     except Exception:
         pass
     rows = []
@@ -212,20 +212,21 @@ def by_shape_table(prof, ops, dev, top=10):
             M, N, K, res, act = key[:5]
         s3 = _is_s3(key)
         # algorithmic bytes: fp32 operands and result; the split kernel reads its operands as 3 bf16 planes (6 B per element)
-        algo = (6.0 if s3 else 4.0) * nb * (M * K + N * K) + 4.0 * nb * M * N * (2 if res else 1)
+        conv = len(key) > 6 and key[6] == "conv"     # implicit GEMM: the input is read once (M x Cin), not as the M x 9 Cin im2col matrix
+        algo = (6.0 if s3 else 4.0) * nb * (M * (K // 9 if conv else K) + N * K) + 4.0 * nb * M * N * (2 if res else 1)
         peak = PEAK_S3_TFLOPS if s3 else PEAK_FP32_MFMA_TFLOPS
-        r = {"M": M, "N": N, "K": K, "batch": nb, "residual": bool(res), "act": act, "calls": v[2], "kernel": "split3" if s3 else "f32",
+        r = {"M": M, "N": N, "K": K, "batch": nb, "residual": bool(res), "act": act, "calls": v[2], "kernel": ("split3" if s3 else "f32") + (" conv3x3" if conv else ""),
              "tflops": round(v[0] / v[1] / 1e9, 1), "frac": round(v[0] / v[1] / 1e9 / peak, 3),
              "share_of_gemm_time": round(v[1] / total_ms, 4), "avg_us": round(v[1] / v[2] * 1e3, 1),
              "algorithmic_MB": round(algo / 1e6, 1), "tile_mode": ops.tile_of(key, dev)}
         p = pmc.get((M, N, K))
-        if p and p.get("kernel", "f32") == r["kernel"]:
+        if p and p.get("kernel", "f32") == r["kernel"].split()[0]:
             r["counter_MB"] = p["counter_MB"]
         rows.append(r)
     return rows
 
 
-def roofline_block(prof, ops, dev, dt, steps, flops_per_step, pmc_file):
+def roofline_block(prof, ops, dev, dt, steps, flops_per_step, pmc_file, pmc_shapes=None):
     """dominant kernel = the GEMM family that holds most of the GEMM time: the bf16x3 split GEMM (priced against the bf16 dense
     MFMA peak / 6 MFMAs per multiply-add) or the fp32-input MFMA GEMM (157.3)"""
     s3 = [p for p in prof if _is_s3(p[2])]
@@ -253,7 +254,7 @@ def roofline_block(prof, ops, dev, dt, steps, flops_per_step, pmc_file):
            "gflop_per_launch": round(gemm_flops / max(1, n_launch) / 1e9, 3),
            "gemm_share_of_step": round(all_ms / (dt * 1e3), 4),
            "end_to_end_frac": round(flops_per_step * steps / dt / 1e12 / peak, 4),
-           "by_shape": by_shape_table(prof, ops, dev)}
+           "by_shape": by_shape_table(prof, ops, dev, pmc_shapes=pmc_shapes or pmc_file.replace("_summary", "_by_shape"))}
     if dom_s3:
         blk["peak_note"] = (f"fp32-equivalent ceiling of the bf16x3 split GEMM: bf16 dense MFMA peak {PEAK_BF16_MFMA_TFLOPS} TFLOP/s / "
                             f"{S3_MFMA_PER_MAC} bf16 MFMAs per multiply-add; `achieved` counts ALGORITHMIC fp32 flops (2 M N K)")
@@ -490,7 +491,8 @@ def main():
                 "metric": "images/sec end-to-end compress at 256x256 with SGIC_GEMM=f32 (every GEMM on v_mfma_f32_32x32x2_f32)",
                 "value": round(B * args.secondary_steps / fdt, 3), "unit": "images/s", "steps": args.secondary_steps,
                 "ms_per_step": round(fdt / args.secondary_steps * 1e3, 3),
-                "roofline": roofline_block(fprof, ops, dev, fdt, args.secondary_steps, gflop * 1e9 * B, "round2_pmc_gemm_summary.json")}
+                "roofline": roofline_block(fprof, ops, dev, fdt, args.secondary_steps, gflop * 1e9 * B, "round2_pmc_f32_gemm_summary.json",
+                                           "round2_pmc_f32_gemm_by_shape.json")}
         if world == 1 and not args.no_cpu_baseline and not args.small and not dec_primary:
             res["cpu_baseline"] = cpu_baseline(sd, clip_sd, cfg, clip_cfg)
         print(json.dumps(res), flush=True)

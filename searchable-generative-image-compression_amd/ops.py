@@ -770,7 +770,7 @@ def conv3x3(x_halo, w, bias, B, H, W, Cin, Cout, residual=None, act=ACT_NONE, ou
             if _pick_and_launch(key, launch3, B * H * W * Cout >= (1 << 20), modes=(1, 2, 3, 5)):
                 return out
         if PROFILE is not None:
-            PROFILE.append((2.0 * B * H * W * Cout * 9 * Cin, (B * H * W, Cout, 9 * Cin, residual is not None, act, "s3")))
+            PROFILE.append((2.0 * B * H * W * Cout * 9 * Cin, (B * H * W, Cout, 9 * Cin, residual is not None, act, "s3", "conv")))
         return out
 
     def launch(mode, prof=None):
@@ -785,7 +785,7 @@ def conv3x3(x_halo, w, bias, B, H, W, Cin, Cout, residual=None, act=ACT_NONE, ou
         if _pick_and_launch(key, launch, B * H * W * Cout >= (1 << 20)):   # conv outputs never alias their residual
             return out
     if PROFILE is not None:   # the implicit-GEMM convolution is the same kernel: M = B*H*W, N = Cout, K = 9*Cin
-        PROFILE.append((2.0 * B * H * W * Cout * 9 * Cin, (B * H * W, Cout, 9 * Cin, residual is not None, act)))
+        PROFILE.append((2.0 * B * H * W * Cout * 9 * Cin, (B * H * W, Cout, 9 * Cin, residual is not None, act, "f32", "conv")))
     return out
 
 

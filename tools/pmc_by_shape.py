@@ -56,7 +56,7 @@ for i, rec in enumerate(shapes):
     key, fl, ms = rec[0], rec[1], rec[2]
     k = tuple(key[:3]) if key[0] != "batched" else tuple(key[2:5])
     a = agg.setdefault(k, dict(calls=0, fetch=0.0, write=0.0, busy=0.0, act=0.0, ms=0.0, flops=0.0, res=bool(key[3]) if key[0] != "batched" else False,
-                               s3=is_s3(key)))
+                               s3=is_s3(key), conv=len(key) > 6 and key[6] == "conv"))
     a["calls"] += 1
     a["fetch"] += fetch[i]
     a["write"] += write[i]
@@ -67,7 +67,8 @@ for i, rec in enumerate(shapes):
 rows = []
 for (M, N, K), a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
     # the split kernel reads its operands as three bf16 planes (6 B per element)
-    algo = (6.0 if a["s3"] else 4.0) * (M * K + N * K) + 4.0 * M * N * (2 if a["res"] else 1)
+    # (an implicit-GEMM convolution reads its input once: M x Cin, not the M x 9 Cin im2col matrix)
+    algo = (6.0 if a["s3"] else 4.0) * (M * (K // 9 if a["conv"] else K) + N * K) + 4.0 * M * N * (2 if a["res"] else 1)
     cnt = (2 * a["fetch"] + a["write"]) * 1024 / a["calls"]
     rows.append({"shape": [M, N, K], "kernel": "split3" if a["s3"] else "f32", "calls": a["calls"], "algorithmic_MB": round(algo / 1e6, 1), "counter_MB": round(cnt / 1e6, 1),
                  "counter_over_algorithmic": round(cnt / algo, 2), "fetch_MB_x2": round(2 * a["fetch"] * 1024 / a["calls"] / 1e6, 1),
