@@ -142,8 +142,8 @@ def test_every_reference_stream_decodes(setup):
         json.dump({"streams_decoded": decoded, "total": int(len(g["names"])), "repaired_by_retry": report, "harmless_index_flips": idx_flips},
                   open(os.path.join(out, "stream_parity_decode.json"), "w"))
     # a flip is a chance event (a sigma within ~1e-7 relative of a bin edge, where two fp32 implementations disagree): about 2 are
-    # expected over the 196 608 coded positions of this fixture whatever the GEMM arithmetic (observed: 1 with SGIC_GEMM=f32, 4
-    # with the default split GEMM, at identical error levels against the reference's activations); every one must be REPAIRED
+    # expected over the 196 608 coded positions of this fixture (observed: 1 with SGIC_GEMM=f32, 4 with the default split GEMM, at
+    # identical error levels against the reference's activations; DESIGN section 4 on why the rates differ); every one must be REPAIRED
     assert repaired <= 6 and idx_flips <= 8
 
 
