@@ -40,6 +40,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define AT_LDK 68     // padded row stride (floats) of the K tile: 272 B -> conflict-free ds_read_b128
 #define AT_LDV 64
 #define AT_TILE (AT_KT * AT_LDK + AT_KT * AT_LDV)   // floats of one unit's K+V tile (16.5 KiB)
+// S3 variant (attn_mode bit 3): S^T = K . Q^T as a bf16x3 split product on v_mfma_f32_32x32x16_bf16 (gemm_split.hip's
+// arithmetic: three bf16 pieces per fp32 operand, six MFMAs per 16 d, fp32 accumulate -- fp32-accurate, 6/16 of the matrix-pipe
+// time of the fp32 MFMA).  K is split while it is staged (a tile is shared by the workgroup's four waves: 8 elements per
+// thread), Q once per item into registers; the K tile lives in LDS as three bf16 planes [32 keys][64 d] with a 144-byte row
+// stride (conflict-free ds_read_b128).  The S^T accumulator layout is that of the fp32 MFMA, so the softmax and
+// O^T += V^T . P^T (fp32 MFMA, P straight from the accumulators) are unchanged.
+#define AT_K3_ROWB 144                                   // bytes per key row of a K plane: 128 data + 16 pad
+#define AT_K3_FLOATS (3 * AT_KT * AT_K3_ROWB / 4)        // the three K planes, in floats (13.5 KiB)
+typedef __bf16 at_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned at_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned at_u32x2 __attribute__((ext_vector_type(2)));
 #define AT_RAG_MAXL 960                              // ragged-row path: q[64] + p[L] live in a wave-private 4 KiB LDS slice
 #define AT_RAG_SLICE (64 + AT_RAG_MAXL)
 
@@ -154,9 +165,11 @@ __device__ void attn_ragged_row(const AttnArgs &a, int unit, int tok, float *wl 
 // LDS: NBUF x UP regions of one (K tile | V tile); UP = units a workgroup can span (1 when nq % ipw == 0, else 2).
 static_assert(4 * AT_RAG_SLICE <= AT_TILE, "ragged-row slices must fit the smallest LDS configuration");
 
-template <int NBUF, int UP>
-__global__ __launch_bounds__(256, (NBUF * UP >= 4) ? 2 : 3) void attn_f32_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[NBUF * UP * AT_TILE];
+template <int NBUF, int UP, bool S3>
+__global__ __launch_bounds__(256, (NBUF * UP >= 4 || (S3 && UP > 1)) ? 2 : 3) void attn_f32_kernel(AttnArgs a) {
+  constexpr int KF = S3 ? AT_K3_FLOATS : AT_KT * AT_LDK;   // floats of the K part of a staged tile
+  constexpr int TILE = KF + AT_KT * AT_LDV;
+  __shared__ __attribute__((aligned(16))) float smem[NBUF * UP * TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   int p = blockIdx.x;
@@ -205,15 +218,33 @@ __global__ __launch_bounds__(256, (NBUF * UP >= 4) ? 2 : 3) void attn_f32_kernel
   const long q_row = at_row(a, seq, q_tok_c);
   const int hc = head * 64;
 
-  // Q^T fragment: lane (q, h) holds Q[q][(2c+h)*4 + t], c=0..7, t=0..3  (pairs with the K read below)
-  float qf[32];
+  // Q^T fragment.  fp32 MFMA: lane (q, h) holds Q[q][(2c+h)*4 + t], c=0..7, t=0..3  (pairs with the K read below).
+  // S3: lane (q, h) holds, per 16-d step c = 0..3, the three bf16 pieces of Q[q][16c + 8h + 0..7].
+  float qf[S3 ? 1 : 32];
+  at_bf16x8 q3[S3 ? 4 : 1][3];
   {
     const float *qp = a.q + q_row * a.ldq + hc;
+    if constexpr (S3) {
 #pragma unroll
-    for (int c = 0; c < 8; c++) {
-      const f32x4 v4 = *reinterpret_cast<const f32x4 *>(qp + (2 * c + lh) * 4);
+      for (int c = 0; c < 4; c++) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(qp + 16 * c + 8 * lh), v1 = *reinterpret_cast<const f32x4 *>(qp + 16 * c + 8 * lh + 4);
+        at_u32x4 p1, p2, p3;
+        unsigned a0, b0, c0;
+        s3_split_pair(v0[0] * a.scale, v0[1] * a.scale, a0, b0, c0); p1[0] = a0, p2[0] = b0, p3[0] = c0;
+        s3_split_pair(v0[2] * a.scale, v0[3] * a.scale, a0, b0, c0); p1[1] = a0, p2[1] = b0, p3[1] = c0;
+        s3_split_pair(v1[0] * a.scale, v1[1] * a.scale, a0, b0, c0); p1[2] = a0, p2[2] = b0, p3[2] = c0;
+        s3_split_pair(v1[2] * a.scale, v1[3] * a.scale, a0, b0, c0); p1[3] = a0, p2[3] = b0, p3[3] = c0;
+        q3[c][0] = __builtin_bit_cast(at_bf16x8, p1);
+        q3[c][1] = __builtin_bit_cast(at_bf16x8, p2);
+        q3[c][2] = __builtin_bit_cast(at_bf16x8, p3);
+      }
+    } else {
 #pragma unroll
-      for (int t = 0; t < 4; t++) qf[c * 4 + t] = v4[t] * a.scale;
+      for (int c = 0; c < 8; c++) {
+        const f32x4 v4 = *reinterpret_cast<const f32x4 *>(qp + (2 * c + lh) * 4);
+#pragma unroll
+        for (int t = 0; t < 4; t++) qf[c * 4 + t] = v4[t] * a.scale;
+      }
     }
   }
 
@@ -245,14 +276,26 @@ __global__ __launch_bounds__(256, (NBUF * UP >= 4) ? 2 : 3) void attn_f32_kernel
       rv[i] = *reinterpret_cast<const f32x4 *>(a.v + row * a.ldv + hcol + c4 * 4);
     }
   };
-  auto store_stage = [&](float *region) {
+  // K/V registers of one staged tile -> an LDS region (S3: K goes in as three bf16 planes, 8 bytes per thread, row and plane)
+  auto store_kv = [&](float *region, const f32x4 *k2, const f32x4 *v2) {
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-      *reinterpret_cast<f32x4 *>(region + (kr + 16 * i) * AT_LDK + c4 * 4) = rk[i];
-      *reinterpret_cast<f32x4 *>(region + AT_KT * AT_LDK + (kr + 16 * i) * AT_LDV + c4 * 4) = rv[i];
+      if constexpr (S3) {
+        unsigned a0, b0, c0, a1, b1, c1;
+        s3_split_pair(k2[i][0], k2[i][1], a0, b0, c0);
+        s3_split_pair(k2[i][2], k2[i][3], a1, b1, c1);
+        unsigned char *kb = reinterpret_cast<unsigned char *>(region) + (kr + 16 * i) * AT_K3_ROWB + c4 * 8;
+        *reinterpret_cast<at_u32x2 *>(kb) = at_u32x2{a0, a1};
+        *reinterpret_cast<at_u32x2 *>(kb + AT_KT * AT_K3_ROWB) = at_u32x2{b0, b1};
+        *reinterpret_cast<at_u32x2 *>(kb + 2 * AT_KT * AT_K3_ROWB) = at_u32x2{c0, c1};
+      } else {
+        *reinterpret_cast<f32x4 *>(region + (kr + 16 * i) * AT_LDK + c4 * 4) = k2[i];
+      }
+      *reinterpret_cast<f32x4 *>(region + KF + (kr + 16 * i) * AT_LDV + c4 * 4) = v2[i];
     }
   };
-  auto region = [&](int buf, int u) { return smem + (buf * UP + u) * AT_TILE; };
+  auto store_stage = [&](float *region) { store_kv(region, rk, rv); };
+  auto region = [&](int buf, int u) { return smem + (buf * UP + u) * TILE; };
 
   // Ragged key tail: L = 289 and 545 are 9 / 17 full key tiles plus ONE key.  A 32-key MFMA tile for one key is
   // 97 % padding, so a tail of <= 2 keys is folded into the online softmax on the VALU instead (a rank-1 update).
@@ -265,14 +308,32 @@ __global__ __launch_bounds__(256, (NBUF * UP >= 4) ? 2 : 3) void attn_f32_kernel
     f32x16 sb;
 #pragma unroll
     for (int e = 0; e < 16; e++) s[e] = 0.f, sb[e] = 0.f;
+    if constexpr (S3) {
+      // four 16-d steps, six bf16 MFMAs each (terms smallest first, as gemm_split.hip); steps alternate between two accumulators
+      const unsigned char *kb = reinterpret_cast<const unsigned char *>(sK) + lq * AT_K3_ROWB + lh * 16;
 #pragma unroll
-    for (int c = 0; c < 4; c++) {   // two independent accumulation chains (dims 0-31 | 32-63), interleaved
-      const f32x4 ka = *reinterpret_cast<const f32x4 *>(&sK[lq * AT_LDK + (2 * c + lh) * 4]);
-      const f32x4 kb = *reinterpret_cast<const f32x4 *>(&sK[lq * AT_LDK + (2 * (c + 4) + lh) * 4]);
+      for (int c = 0; c < 4; c++) {
+        const at_bf16x8 k1 = *reinterpret_cast<const at_bf16x8 *>(kb + c * 32);
+        const at_bf16x8 k2 = *reinterpret_cast<const at_bf16x8 *>(kb + AT_KT * AT_K3_ROWB + c * 32);
+        const at_bf16x8 k3 = *reinterpret_cast<const at_bf16x8 *>(kb + 2 * AT_KT * AT_K3_ROWB + c * 32);
+        f32x16 &t = (c & 1) ? sb : s;
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k3, q3[c][0], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q3[c][2], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, q3[c][1], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, q3[c][0], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q3[c][1], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q3[c][0], t, 0, 0, 0);
+      }
+    } else {
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[t], qf[c * 4 + t], s, 0, 0, 0);
-        sb = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[t], qf[(c + 4) * 4 + t], sb, 0, 0, 0);
+      for (int c = 0; c < 4; c++) {   // two independent accumulation chains (dims 0-31 | 32-63), interleaved
+        const f32x4 ka = *reinterpret_cast<const f32x4 *>(&sK[lq * AT_LDK + (2 * c + lh) * 4]);
+        const f32x4 kb = *reinterpret_cast<const f32x4 *>(&sK[lq * AT_LDK + (2 * (c + 4) + lh) * 4]);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[t], qf[c * 4 + t], s, 0, 0, 0);
+          sb = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[t], qf[(c + 4) * 4 + t], sb, 0, 0, 0);
+        }
       }
     }
 #pragma unroll
@@ -344,7 +405,7 @@ __global__ __launch_bounds__(256, (NBUF * UP >= 4) ? 2 : 3) void attn_f32_kernel
         if (two) issue_stage(key0 + AT_KT, seqB, hcB);
         else if (kt + 2 < ntiles) issue_stage(key0 + 2 * AT_KT, seqA, hcA);
       }
-      if (active) softmax_pv(reg + AT_KT * AT_LDK, s, key0);
+      if (active) softmax_pv(reg + KF, s, key0);
       if (two && kt + 1 < ntiles) {
         store_stage(region(nxt, UP - 1));
         if (kt + 2 < ntiles) issue_stage(key0 + 2 * AT_KT, seqA, hcA);
@@ -370,14 +431,7 @@ __global__ __launch_bounds__(256, (NBUF * UP >= 4) ? 2 : 3) void attn_f32_kernel
     for (int kt = 0; kt < ntiles; ++kt) {
       const int key0 = kt * AT_KT;
       store_stage(region(0, 0));
-      if (two) {
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-          float *r1 = region(0, UP - 1);
-          *reinterpret_cast<f32x4 *>(r1 + (kr + 16 * i) * AT_LDK + c4 * 4) = rk2[i];
-          *reinterpret_cast<f32x4 *>(r1 + AT_KT * AT_LDK + (kr + 16 * i) * AT_LDV + c4 * 4) = rv2[i];
-        }
-      }
+      if (two) store_kv(region(0, UP - 1), rk2, rv2);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (kt + 1 < ntiles) {  // next tile's loads fly during this tile's 64 MFMAs
@@ -388,7 +442,7 @@ __global__ __launch_bounds__(256, (NBUF * UP >= 4) ? 2 : 3) void attn_f32_kernel
         const float *reg = region(0, mine);
         f32x16 s;
         compute_s(reg, s);
-        softmax_pv(reg + AT_KT * AT_LDK, s, key0);
+        softmax_pv(reg + KF, s, key0);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // tile fully consumed before the next store
@@ -405,8 +459,14 @@ __global__ __launch_bounds__(256, (NBUF * UP >= 4) ? 2 : 3) void attn_f32_kernel
 #pragma unroll
       for (int c = 0; c < 8; c++) {
         const f32x4 k4 = *reinterpret_cast<const f32x4 *>(kp + (2 * c + lh) * 4);
+        if constexpr (S3) {   // the fp32 q is not kept in registers: one more (L2-hot) read for the single tail key
+          const f32x4 q4 = *reinterpret_cast<const f32x4 *>(a.q + q_row * a.ldq + hc + (2 * c + lh) * 4);
 #pragma unroll
-        for (int t = 0; t < 4; t++) sc = fmaf(k4[t], qf[c * 4 + t], sc);
+          for (int t = 0; t < 4; t++) sc = fmaf(k4[t], q4[t] * a.scale, sc);
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; t++) sc = fmaf(k4[t], qf[c * 4 + t], sc);
+        }
       }
       sc += __shfl_xor(sc, 32);
       if (bias_base) sc += bias_base[key];
@@ -467,10 +527,14 @@ static int attention_any(const float *d_q, int ldq, const float *d_k, int ldk, c
   SGIC_REQUIRE((((uintptr_t)d_q | (uintptr_t)d_k | (uintptr_t)d_v | (uintptr_t)d_out) & 15) == 0 && ((uintptr_t)d_planes & 7) == 0, "16-byte alignment");
   SGIC_REQUIRE(!d_planes || plane_rows >= (long)nseq * L, "plane rows");
   SGIC_REQUIRE(!d_bias || (L & 3) == 0, "bias needs L % 4 == 0");
-  const int mode = opts ? opts->attn_mode : 0;
-  // attn_mode: 0 = default (see below); odd = single LDS buffer (two barriers per tile), even = double-buffered LDS (one
-  // barrier per tile); modes 3,4 / 5,6 add the start-up stagger of 4096 / 8192 cycles per hardware wave slot
-  SGIC_REQUIRE(mode >= 0 && mode <= 6, "attn_mode 0..6");
+  const int mode_all = opts ? opts->attn_mode : 0;
+  // attn_mode: low 3 bits: 0 = default (see below); odd = single LDS buffer (two barriers per tile), even = double-buffered LDS
+  // (one barrier per tile); modes 3,4 / 5,6 add the start-up stagger of 4096 / 8192 cycles per hardware wave slot.
+  // bit 3 (+8): S^T = K . Q^T as a bf16x3 split product on the bf16 matrix pipe (fp32-accurate; results differ in the last bits
+  // from the fp32-MFMA variant, and are again identical for every mode of the same variant)
+  SGIC_REQUIRE(mode_all >= 0 && mode_all <= 14 && (mode_all & 7) <= 6, "attn_mode 0..6 (+8)");
+  const bool s3 = (mode_all & 8) != 0;
+  const int mode = mode_all & 7;
   const long units = (long)nseq * nheads;
   const int rem = L % 32;
   const int rag = (rem >= 1 && rem <= 2 && L >= 64 && L <= AT_RAG_MAXL) ? rem : 0;   // ragged query rows -> VALU path
@@ -497,12 +561,20 @@ static int attention_any(const float *d_q, int ldq, const float *d_k, int ldk, c
   a.stagger_cycles = eff > 2 ? 4096 * ((eff - 1) / 2) : 0;
   const int per_cu = (!single && up2) ? 2 : 3;
   a.first_round = per_cu * 256;
-  if (up2) {
-    if (single) launch_attn(attn_f32_kernel<1, 2>, grid, st, a);
-    else launch_attn(attn_f32_kernel<2, 2>, grid, st, a);
+  if (s3) {
+    if (up2) {
+      if (single) launch_attn(attn_f32_kernel<1, 2, true>, grid, st, a);
+      else launch_attn(attn_f32_kernel<2, 2, true>, grid, st, a);
+    } else {
+      if (single) launch_attn(attn_f32_kernel<1, 1, true>, grid, st, a);
+      else launch_attn(attn_f32_kernel<2, 1, true>, grid, st, a);
+    }
+  } else if (up2) {
+    if (single) launch_attn(attn_f32_kernel<1, 2, false>, grid, st, a);
+    else launch_attn(attn_f32_kernel<2, 2, false>, grid, st, a);
   } else {
-    if (single) launch_attn(attn_f32_kernel<1, 1>, grid, st, a);
-    else launch_attn(attn_f32_kernel<2, 1>, grid, st, a);
+    if (single) launch_attn(attn_f32_kernel<1, 1, false>, grid, st, a);
+    else launch_attn(attn_f32_kernel<2, 1, false>, grid, st, a);
   }
   return sgic::check_launch("attn_f32_kernel");
 }

@@ -504,7 +504,7 @@ def layernorm(x, gamma, beta, out=None, eps=1e-5, act=ACT_NONE, M=None, x_seg=(0
     return out
 
 
-def attention(q, k, v, out, L, nseq, nheads, rowmap=None, bias=None, biasvar=None, scale=0.125, mode=None, to_gemm=False):
+def attention(q, k, v, out, L, nseq, nheads, rowmap=None, bias=None, biasvar=None, scale=0.125, mode=None, to_gemm=False, precision=None):
     """q,k,v,out: 2-D row-strided views (rows x nheads*64).  mode: force attn_mode (tests / tools).
     to_gemm=True: the output feeds only the out-projection GEMM -> written as bf16x3 Planes over q's row space when the split
     path is active (`out` may be None or a Planes object to reuse); otherwise into the fp32 `out` as always."""
@@ -527,20 +527,22 @@ def attention(q, k, v, out, L, nseq, nheads, rowmap=None, bias=None, biasvar=Non
     if biasvar is not None:
         assert biasvar.dtype == torch.int32 and biasvar.numel() == nseq
 
+    s3 = 8 if (precision or PRECISION) == "split3" else 0     # attn_mode bit 3: S^T = K Q^T as a bf16x3 split product
+
     def launch(m):
         if pl is not None:
             call("sgic_attention_split3_f32", _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(pl.t), ctypes.c_long(pl.rows), L, nseq, nheads,
-                 _p(rowmap), _p(bias), _p(biasvar), float(scale), launch_opts(0, m, None))
+                 _p(rowmap), _p(bias), _p(biasvar), float(scale), launch_opts(0, m | s3, None))
         else:
             call("sgic_attention_f32", _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), ldo, L, nseq, nheads, _p(rowmap), _p(bias),
-                 _p(biasvar), float(scale), launch_opts(0, m, None))
+                 _p(biasvar), float(scale), launch_opts(0, m | s3, None))
 
     # K/V ring depth (single buffer + more workgroups per CU vs double buffer + one barrier per tile) depends on L and
     # on how many workgroups the launch has -> tuned per shape like the GEMM tiles; results are identical.
     if mode is None:
         mode = 0
         if nseq * nheads * L >= 4096:
-            key = ("attn", nseq, L, nheads, int(bias is not None))
+            key = ("attn3" if s3 else "attn", nseq, L, nheads, int(bias is not None))
             mode = _lookup(key)
             if mode is None:
                 mode = 0

@@ -324,14 +324,15 @@ def test_attention_vs_torch(L, nseq, heads, bias):
     old = ops.AUTOTUNE
     ops.AUTOTUNE = False
     try:
-        first = None
-        for mode in (0,) + ops.ATTN_MODES:
-            out = torch.full((nseq * L, D), float("nan"), device="cuda:0")
-            ops.attention(d[:, :D], d[:, D:2 * D], d[:, 2 * D:], out, L, nseq, heads, bias=b.cuda() if bias else None,
-                          biasvar=var.cuda() if bias else None, mode=mode)
-            err = float((out.cpu().double() - ref).abs().max())
-            assert err < 2e-5, (L, mode, err)
-            first = out if first is None else first
-            assert torch.equal(out, first), (L, mode)
+        for precision in ("f32", "split3"):      # fp32-MFMA scores / bf16x3 split scores (attn_mode bit 3): each bitwise stable over its modes
+            first = None
+            for mode in (0,) + ops.ATTN_MODES:
+                out = torch.full((nseq * L, D), float("nan"), device="cuda:0")
+                ops.attention(d[:, :D], d[:, D:2 * D], d[:, 2 * D:], out, L, nseq, heads, bias=b.cuda() if bias else None,
+                              biasvar=var.cuda() if bias else None, mode=mode, precision=precision)
+                err = float((out.cpu().double() - ref).abs().max())
+                assert err < 2e-5, (L, mode, precision, err)
+                first = out if first is None else first
+                assert torch.equal(out, first), (L, mode, precision)
     finally:
         ops.AUTOTUNE = old
