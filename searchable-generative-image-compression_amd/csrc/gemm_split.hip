@@ -94,16 +94,21 @@ struct S3Args {
 // i.e. the one barrier per slice sits 6 BN/2 MFMAs before the slice's end, where every LDS read of the current stage has been
 // issued, and the MFMAs left cover the latency of the first reads of the next stage: the matrix pipe never waits at the seam
 // and no fragment is held twice (acc 4 BM BN + W 12 BN + A 24 registers).
-// NS = register sets of staged K slices: 1 = loads run two slices ahead (large tiles: a slice is >= 1536 MFMA cycles, longer than a
-// load); NS > 1 = the loads of slice kt + 1 + NS are issued at slice kt (small tiles of under-filled launches: a slice is 100-400
-// MFMA cycles and one workgroup per CU has nothing else to hide a ~2 us load behind).
-template <int WAVES_M, int WAVES_N, int BM, int BN, int NS>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (2 * 3 * 16 * (BM * WAVES_M + BN * WAVES_N) * 64 <= 80 * 1024 && WAVES_M * WAVES_N == 8) ? 2 : 1)
+// NS = register sets of staged K stages: 1 = loads run two stages ahead (large tiles: a stage is >= 1536 MFMA cycles, longer than a
+// load); NS > 1 = the loads of stage kt + 1 + NS are issued at stage kt (small tiles of under-filled launches: a stage is a few
+// hundred MFMA cycles and one workgroup per CU has nothing else to hide a ~2 us load behind).
+// KS = 32-k slices per LDS stage (rows of 64 KS bytes): 2 for the small tiles when K % 64 == 0 -- one barrier and one round of
+// exposed LDS latency per 64 k instead of per 32 k, which is what bounds a launch of one wave per SIMD.
+template <int WAVES_M, int WAVES_N, int BM, int BN, int NS, int KS>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (2 * 3 * 16 * (BM * WAVES_M + BN * WAVES_N) * 64 * KS <= 80 * 1024 && WAVES_M * WAVES_N == 8) ? 2 : 1)
 void gemm_split3_kernel(S3Args g) {
+  static_assert(KS == 1 || KS == 2, "32-k slices per stage");
   constexpr int NT = 64 * WAVES_M * WAVES_N, TM = 16 * BM * WAVES_M, TN = 16 * BN * WAVES_N;
-  constexpr int CA = (TM * 4 + NT - 1) / NT, CW = (TN * 4 + NT - 1) / NT;   // 16-byte chunks per thread, plane and stage
-  constexpr int APLANE = TM * 64, WPLANE = TN * 64, STAGE = 3 * (APLANE + WPLANE);
+  constexpr int ROWB = 64 * KS, SL = 4 * KS;                                    // bytes / 16-byte slots per LDS row
+  constexpr int CA = (TM * SL + NT - 1) / NT, CW = (TN * SL + NT - 1) / NT;     // 16-byte chunks per thread, plane and stage
+  constexpr int APLANE = TM * ROWB, WPLANE = TN * ROWB, STAGE = 3 * (APLANE + WPLANE);
   constexpr int HB = BN >= 2 ? BN / 2 : BN;     // column blocks in the "hi" half of W (BN == 1: no halves)
+  static_assert((NT / SL) % 16 == 0, "a thread's staged rows must share their swizzle term");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN, nwg = tiles_m * tiles_n;
@@ -119,21 +124,26 @@ void gemm_split3_kernel(S3Args g) {
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / WAVES_N) * (16 * BM), wn = (wave % WAVES_N) * (16 * BN);
-  // LDS image of a stage: per plane, rows of 64 B (32 k) unpadded; the 16-byte slot s of row r sits at slot s ^ f((r >> 2) & 3),
-  // f = (0, 2, 3, 1): conflict-free for the ds_read_b128 lane groups {0-3,12-15,20-27}, ... of a fragment read
-  // (row = lane & 15, slot = lane >> 4) and for ds_write_b128 (8 consecutive lanes = 2 whole rows)
+  // LDS image of a stage: per plane, rows of 64 KS bytes unpadded; the 16-byte slot s of row r sits at slot s ^ swz(r):
+  //   KS = 1: swz = f((r >> 2) & 3), f = (0, 2, 3, 1);   KS = 2: swz = (r >> 1) & 7
+  // -- conflict-free for the ds_read_b128 lane groups {0-3,12-15,20-27}, ... of a fragment read (row = lane & 15,
+  // slot = 4 slice + (lane >> 4)) and for ds_write_b128 (8 consecutive lanes = whole rows)
   auto swz = [](int row) {
-    const int gq = (row >> 2) & 3;
-    return (((gq ^ (gq >> 1)) & 1) << 1) | (gq >> 1);
+    if constexpr (KS == 1) {
+      const int gq = (row >> 2) & 3;
+      return (((gq ^ (gq >> 1)) & 1) << 1) | (gq >> 1);
+    } else {
+      return (row >> 1) & 7;
+    }
   };
-  // staging map: chunk q = tid + i NT of a plane -> (row q >> 2, slot q & 3); NT / 4 is a multiple of 16, so the swizzle of a
+  // staging map: chunk q = tid + i NT of a plane -> (row q / SL, slot q % SL); NT / SL is a multiple of 16, so the swizzle of a
   // thread's rows does not depend on i
-  const int srow = tid >> 2, sslot = tid & 3;
-  const int sw = srow * 64 + ((sslot ^ swz(srow)) * 16);
+  const int srow = tid / SL, sslot = tid % SL;
+  const int sw = srow * ROWB + ((sslot ^ swz(srow)) * 16);
   const unsigned short *aptr[CA], *wptr[CW];
 #pragma unroll
   for (int i = 0; i < CA; i++) {
-    const int am = min(m0 + srow + i * (NT / 4), g.M - 1);
+    const int am = min(m0 + srow + i * (NT / SL), g.M - 1);
     if (g.conv_C) {   // top-left pixel of the 3x3 patch in the halo buffer
       const int hw = g.conv_H * g.conv_W, b = am / hw, r = am - b * hw, y = r / g.conv_W, x = r - y * g.conv_W;
       aptr[i] = g.A + (((size_t)b * (g.conv_H + 2) + y) * (g.conv_W + 2) + x) * g.conv_C + sslot * 8;
@@ -142,13 +152,13 @@ void gemm_split3_kernel(S3Args g) {
     }
   }
 #pragma unroll
-  for (int i = 0; i < CW; i++) wptr[i] = g.W + (size_t)min(n0 + srow + i * (NT / 4), g.N - 1) * g.K + sslot * 8;
-  const bool a_on = CA * NT == TM * 4 || srow < TM, w_on = CW * NT == TN * 4 || srow < TN;   // tiles smaller than a pass
+  for (int i = 0; i < CW; i++) wptr[i] = g.W + (size_t)min(n0 + srow + i * (NT / SL), g.N - 1) * g.K + sslot * 8;
+  const bool a_on = CA * NT == TM * SL || srow < TM, w_on = CW * NT == TN * SL || srow < TN;   // tiles smaller than a pass
   u32x4 ra[NS][3][CA], rw[NS][3][CW];
   auto issue = [&](int k0, auto set_c) {
     constexpr int S = decltype(set_c)::value;
     int ka = k0;
-    if (g.conv_C) {   // wave-uniform: the tap this K slice belongs to
+    if (g.conv_C) {   // wave-uniform: the tap this K stage belongs to (conv_C % (32 KS) == 0: a stage never straddles a tap)
       const int tap = k0 / g.conv_C, c0 = k0 - tap * g.conv_C, ky = tap / 3, kx = tap - 3 * ky;
       ka = (ky * (g.conv_W + 2) + kx) * g.conv_C + c0;
     }
@@ -167,11 +177,11 @@ void gemm_split3_kernel(S3Args g) {
     for (int p = 0; p < 3; p++) {
       if (a_on) {
 #pragma unroll
-        for (int i = 0; i < CA; i++) *reinterpret_cast<u32x4 *>(base + p * APLANE + i * (NT / 4) * 64) = ra[S][p][i];
+        for (int i = 0; i < CA; i++) *reinterpret_cast<u32x4 *>(base + p * APLANE + i * (NT / SL) * ROWB) = ra[S][p][i];
       }
       if (w_on) {
 #pragma unroll
-        for (int i = 0; i < CW; i++) *reinterpret_cast<u32x4 *>(base + 3 * APLANE + p * WPLANE + i * (NT / 4) * 64) = rw[S][p][i];
+        for (int i = 0; i < CW; i++) *reinterpret_cast<u32x4 *>(base + 3 * APLANE + p * WPLANE + i * (NT / SL) * ROWB) = rw[S][p][i];
       }
     }
   };
@@ -181,21 +191,24 @@ void gemm_split3_kernel(S3Args g) {
 #pragma unroll
     for (int j = 0; j < BN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int l16 = lane & 15, lq = lane >> 4;
-  // fragment address of (row base + l16, slot lq): block bases are multiples of 16 rows, so the swizzle term is the lane's own
-  const int foff = l16 * 64 + ((lq ^ swz(l16)) * 16);
-  const int aoff = wm * 64 + foff, boff = 3 * APLANE + wn * 64 + foff;
+  // fragment address of (row base + l16, slot 4 slice + lq): block bases are multiples of 16 rows, so the swizzle term is the
+  // lane's own
+  int foff[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ks++) foff[ks] = l16 * ROWB + (((4 * ks + lq) ^ swz(l16)) * 16);
+  const int abase = wm * ROWB, bbase = 3 * APLANE + wn * ROWB;
   bf16x8 wf[3][BN], af[2][3];
-  auto read_w = [&](int buf, int j) {
-    const unsigned char *base = smem + buf * STAGE + boff + j * 16 * 64;
+  auto read_w = [&](int buf, int j, int ks) {
+    const unsigned char *base = smem + buf * STAGE + bbase + j * 16 * ROWB + foff[ks];
 #pragma unroll
     for (int p = 0; p < 3; p++) wf[p][j] = *reinterpret_cast<const bf16x8 *>(base + p * WPLANE);
   };
-  auto read_a = [&](int buf, int i, int set) {
-    const unsigned char *base = smem + buf * STAGE + aoff + i * 16 * 64;
+  auto read_a = [&](int buf, int i, int set, int ks) {
+    const unsigned char *base = smem + buf * STAGE + abase + i * 16 * ROWB + foff[ks];
 #pragma unroll
     for (int p = 0; p < 3; p++) af[set][p] = *reinterpret_cast<const bf16x8 *>(base + p * APLANE);
   };
-  // one 16 x 16 block over the slice: the six terms, smallest first -- THE order of the arithmetic (see the header)
+  // one 16 x 16 block over a 32-k slice: the six terms, smallest first -- THE order of the arithmetic (see the header)
   auto block = [&](int i, int j, int set) {
     f32x4 c = acc[i][j];
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][j], af[set][2], c, 0, 0, 0);   // a3 w1
@@ -206,56 +219,67 @@ void gemm_split3_kernel(S3Args g) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][j], af[set][0], c, 0, 0, 0);   // a1 w1
     acc[i][j] = c;
   };
-  const int nk = g.K / 32;
+  constexpr int BKS = 32 * KS;
+  const int nk = g.K / BKS;
   issue(0, IntC<0>{});
   store(0, IntC<0>{});
   if constexpr (NS == 1) {
-    if (nk > 1) issue(32, IntC<0>{});
+    if (nk > 1) issue(BKS, IntC<0>{});
   } else {
-    // slices 1 .. NS into sets 1 .. NS-1, 0 (slice j lives in set j % NS; set 0 was just stored)
+    // stages 1 .. NS into sets 1 .. NS-1, 0 (stage j lives in set j % NS; set 0 was just stored)
     s3_for<NS>([&](auto u_c) {
       constexpr int J = decltype(u_c)::value + 1;
-      if (J < nk) issue(J * 32, IntC<J % NS>{});
+      if (J < nk) issue(J * BKS, IntC<J % NS>{});
     });
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   // prologue of the rotating schedule: Whi and A row 0 of slice 0
 #pragma unroll
-  for (int j = BN - HB; j < BN; j++) read_w(0, j);
-  read_a(0, 0, 0);
-  // MFMA part of a slice; `more` = a next slice exists (its first fragments are read behind the barrier)
-  auto compute = [&](int cur, bool more) {
+  for (int j = BN - HB; j < BN; j++) read_w(0, j, 0);
+  read_a(0, 0, 0, 0);
+  // MFMA part of ONE 32-k slice (index KSI of its stage).  The slice's first fragments (Whi, A row 0) were read during the
+  // previous slice's tail; its own tail reads the next slice's: slice KSI + 1 of the same stage, or -- behind the stage's one
+  // barrier -- slice 0 of the other stage (`more`: a next stage exists).
+  auto compute = [&](int cur, auto ks_c, bool more) {
+    constexpr int KSI = decltype(ks_c)::value;
+    constexpr bool LAST = KSI == KS - 1;
     const int nxt = cur ^ 1;
     if constexpr (BN >= 2) {
 #pragma unroll
-      for (int j = 0; j < BN - HB; j++) read_w(cur, j);       // Wlo: needed after the Whi blocks of row 0
+      for (int j = 0; j < BN - HB; j++) read_w(cur, j, KSI);       // Wlo: needed after the Whi blocks of row 0
     }
 #pragma unroll
     for (int i = 0; i < BM; i++) {
       const int set = i & 1;
-      if (i + 1 < BM) read_a(cur, i + 1, set ^ 1);
+      if (i + 1 < BM) read_a(cur, i + 1, set ^ 1, KSI);
       // rows 0 and BM-1 run their Whi blocks first
 #pragma unroll
       for (int j = BN - HB; j < BN; j++) block(i, j, set);
       if (i == BM - 1) {
-        if constexpr (NS == 1) {   // one LDS write / global load / fragment read per MFMA instead of clumps (measured +1.5 % end to end)
-          constexpr int NMF1 = 6 * (BM * BN - (BN - HB)), NDW = 3 * (CA + CW), NDR1 = 3 * (BN - HB) + 3 * (BM - 1);
+        if constexpr (LAST) {
+          if constexpr (NS == 1) {   // one LDS write / global load / fragment read per MFMA instead of clumps (measured +1.5 % end to end)
+            constexpr int NMF1 = 6 * (BM * BN - (BN - HB)), NDW = 3 * (CA + CW), NDR1 = 3 * (BN - HB) + 3 * (BM - 1);
 #pragma unroll
-          for (int q = 0; q < NMF1; q++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (q < NDW) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            else if (q < 2 * NDW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            if (q % 4 == 0 && q / 4 < NDR1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            for (int q = 0; q < NMF1; q++) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              if (q < NDW) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+              else if (q < 2 * NDW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+              if (q % 4 == 0 && q / 4 < NDR1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
           }
-        }
-        // every LDS read of stage `cur` has been issued; the writes into `nxt` were issued at the top of the slice
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (more) {
+          // every LDS read of stage `cur` has been issued; the writes into `nxt` were issued at the top of the stage
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          if (more) {
 #pragma unroll
-          for (int j = BN - HB; j < BN; j++) read_w(nxt, j);   // Whi of the next slice (its registers are free now) ...
-          read_a(nxt, 0, BM == 1 ? 0 : (BM & 1));              // ... and A row 0, into the set row BM-1 does not use
+            for (int j = BN - HB; j < BN; j++) read_w(nxt, j, 0);   // Whi of the next slice (its registers are free now) ...
+            read_a(nxt, 0, BM == 1 ? 0 : (BM & 1), 0);              // ... and A row 0, into the set row BM-1 does not use
+          }
+        } else {
+#pragma unroll
+          for (int j = BN - HB; j < BN; j++) read_w(cur, j, KSI + 1);
+          read_a(cur, 0, BM == 1 ? 0 : (BM & 1), KSI + 1);
         }
       }
       if constexpr (BN >= 2) {
@@ -265,34 +289,37 @@ void gemm_split3_kernel(S3Args g) {
     }
   };
   static_assert((BM == 1 && BN == 1) || (BM % 2) == 0, "A row 0 of the next slice must land in set 0, free at that point");
+  auto stage_mfma = [&](int cur, bool more) {
+    s3_for<KS>([&](auto ks_c) { compute(cur, ks_c, more); });
+  };
   if constexpr (NS == 1) {
-    auto slice = [&](int kt, auto store_c, auto issue_c) {
+    auto stage = [&](int kt, auto store_c, auto issue_c) {
       constexpr bool ST = decltype(store_c)::value, IS = decltype(issue_c)::value;
       if constexpr (ST) store((kt & 1) ^ 1, IntC<0>{});
-      if constexpr (IS) issue((kt + 2) * 32, IntC<0>{});
-      compute(kt & 1, ST);
+      if constexpr (IS) issue((kt + 2) * BKS, IntC<0>{});
+      stage_mfma(kt & 1, ST);
     };
     using T = std::true_type;
     using F = std::false_type;
     int kt = 0;
-    for (; kt + 2 < nk; ++kt) slice(kt, T{}, T{});
+    for (; kt + 2 < nk; ++kt) stage(kt, T{}, T{});
     if (kt + 1 < nk) {
-      slice(kt, T{}, F{});
+      stage(kt, T{}, F{});
       ++kt;
     }
-    slice(kt, F{}, F{});
+    stage(kt, F{}, F{});
   } else {
     for (int base = 0; base < nk; base += NS) {
       s3_for<NS>([&](auto u_c) {
         constexpr int U = decltype(u_c)::value;
-        const int kt = base + U;              // base % NS == 0: slice kt + 1 lives in set (U + 1) % NS
+        const int kt = base + U;              // base % NS == 0: stage kt + 1 lives in set (U + 1) % NS
         if (kt < nk) {                        // uniform
           const bool more = kt + 1 < nk;
           if (more) {
             store((kt & 1) ^ 1, IntC<(U + 1) % NS>{});
-            if (kt + 1 + NS < nk) issue((kt + 1 + NS) * 32, IntC<(U + 1) % NS>{});
+            if (kt + 1 + NS < nk) issue((kt + 1 + NS) * BKS, IntC<(U + 1) % NS>{});
           }
-          compute(kt & 1, more);
+          stage_mfma(kt & 1, more);
         }
       });
     }
@@ -418,12 +445,12 @@ extern "C" int sgic_split3_f32(const float *d_x, int ld, int rows, int cols, int
 
 #define SGIC_SPLIT3_TILE_MODES 7
 
-template <int WAVES_M, int WAVES_N, int BM, int BN, int NS>
+template <int WAVES_M, int WAVES_N, int BM, int BN, int NS, int KS = 1>
 static int s3_launch(const S3Args &g, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
   constexpr int NT = 64 * WAVES_M * WAVES_N, TM = 16 * BM * WAVES_M, TN = 16 * BN * WAVES_N;
-  constexpr int LDS = 2 * 3 * (TM + TN) * 64;
+  constexpr int LDS = 2 * 3 * (TM + TN) * 64 * KS;
   static bool attr_set = false;   // idempotent: a race sets the same value twice
-  auto kernel = gemm_split3_kernel<WAVES_M, WAVES_N, BM, BN, NS>;
+  auto kernel = gemm_split3_kernel<WAVES_M, WAVES_N, BM, BN, NS, KS>;
   if (!attr_set) {
     SGIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
@@ -441,8 +468,9 @@ static int s3_mode(const S3Args &g, int mode, hipStream_t st, hipEvent_t e0, hip
   switch (mode) {
     case 1: return s3_launch<2, 4, 4, 4, 1>(g, st, e0, e1);
     case 2: return s3_launch<2, 4, 4, 2, 1>(g, st, e0, e1);
-    case 3: return s3_launch<2, 2, 2, 2, 4>(g, st, e0, e1);
-    case 4: return s3_launch<2, 2, 1, 1, 6>(g, st, e0, e1);
+    // the 32x32 latency tile: 64-k stages when K allows (and, for a convolution, a stage stays inside one tap)
+    case 3: return s3_launch<2, 2, 2, 2, 4>(g, st, e0, e1);   // (64-k stages measured no better for the 64x64 tile)
+    case 4: return (g.K % 64 == 0 && g.conv_C % 64 == 0) ? s3_launch<2, 2, 1, 1, 3, 2>(g, st, e0, e1) : s3_launch<2, 2, 1, 1, 6>(g, st, e0, e1);
     default: return s3_launch<2, 4, 2, 2, 1>(g, st, e0, e1);
   }
 }
