@@ -209,3 +209,18 @@ def test_split_launch_modes_with_row_map_residual_and_planes(ops):
     o3 = ref[1][0].reshape(n, L, N)
     want = (a.double() @ w.double().T + bias.double()).reshape(n, Lt, N)
     assert float((o3[:, :Lt].double() - want).abs().max()) < 1e-4 and float(o3[:, Lt:].abs().max()) == 0.0
+
+
+def test_single_tile_latency(ops):
+    """the B = 1 building block under the split arithmetic: one 64x64 tile, K = 512, by dispatch timestamps (the 32x32
+    latency mode with 64-k stages); the fp32 latency kernel's bound (test_gpu_encoder) is 10 us as well"""
+    a = torch.randn(64, 512, device="cuda")
+    w = torch.randn(64, 512, device="cuda")
+    for _ in range(3):
+        ops.gemm(a, w, precision="split3", tile=4)
+    ops.profile_begin(8)
+    for _ in range(4):
+        ops.gemm(a, w, precision="split3", tile=4)
+    recs = ops.profile_end()
+    best = min(ms for _, ms, _ in recs)
+    assert len(recs) == 4 and best < 0.010, f"64x64x512 split GEMM took {best * 1e3:.1f} us"
