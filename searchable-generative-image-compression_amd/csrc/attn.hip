@@ -48,6 +48,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // O^T += V^T . P^T (fp32 MFMA, P straight from the accumulators) are unchanged.
 #define AT_K3_ROWB 144                                   // bytes per key row of a K plane: 128 data + 16 pad
 #define AT_K3_FLOATS (3 * AT_KT * AT_K3_ROWB / 4)        // the three K planes, in floats (13.5 KiB)
+// ... and O^T += V^T . P^T the same way: V^T is staged as three bf16 planes [64 d][32 keys] (80-byte rows), the keys of a tile in
+// the order the S^T accumulators hold them -- MFMA k-slot (h, j) of 16-key group G is key 16 G + 4 h + (j & 3) + 8 (j >> 2) --
+// so a lane's eight P values of a group are its accumulator elements 8 G .. 8 G + 7 (split in registers after the exp) and its
+// eight V values one 16-byte LDS read.  A staging thread owns one d and one (G, h) octet of keys: eight coalesced 4-byte loads
+// (one key row per wave instruction), one ds_write_b128 per plane.
+#define AT_V3_ROWB 80                                    // bytes per d row of a V^T plane: 64 data + 16 pad (conflict-free b128)
+#define AT_V3_FLOATS (3 * 64 * AT_V3_ROWB / 4)           // the three V^T planes, in floats (15 KiB)
 typedef __bf16 at_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned at_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned at_u32x2 __attribute__((ext_vector_type(2)));
@@ -168,7 +175,8 @@ static_assert(4 * AT_RAG_SLICE <= AT_TILE, "ragged-row slices must fit the small
 template <int NBUF, int UP, bool S3>
 __global__ __launch_bounds__(256, (NBUF * UP >= 4 || (S3 && UP > 1)) ? 2 : 3) void attn_f32_kernel(AttnArgs a) {
   constexpr int KF = S3 ? AT_K3_FLOATS : AT_KT * AT_LDK;   // floats of the K part of a staged tile
-  constexpr int TILE = KF + AT_KT * AT_LDV;
+  constexpr int VF = S3 ? AT_V3_FLOATS : AT_KT * AT_LDV;   // ... and of its V part
+  constexpr int TILE = KF + VF;
   __shared__ __attribute__((aligned(16))) float smem[NBUF * UP * TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -266,18 +274,41 @@ __global__ __launch_bounds__(256, (NBUF * UP >= 4 || (S3 && UP > 1)) ? 2 : 3) vo
   const int seqA = uA / a.nheads, hcA = (uA % a.nheads) * 64;
   const int uB = min(uA + 1, a.nseq * a.nheads - 1);
   const int seqB = uB / a.nheads, hcB = (uB % a.nheads) * 64;
-  f32x4 rk[2], rv[2];
+  // V staging of the S3 variant: thread -> (d = tid & 63, key octet = wave): the eight keys of MFMA k-slots (h, 0..7) of group G,
+  // (G, h) = (wave >> 1, wave & 1)
+  struct VRegs {
+    f32x4 v4[S3 ? 1 : 2];
+    float v1[S3 ? 8 : 1];
+  };
+  f32x4 rk[2];
+  VRegs rv;
+  auto load_v = [&](VRegs &dst, int key0, int sq, int hcol) {
+    if constexpr (S3) {
+      const int kbase = key0 + 16 * (wave >> 1) + 4 * (wave & 1);
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int tok = min(kbase + (j & 3) + 8 * (j >> 2), a.L - 1);   // wave-uniform
+        dst.v1[j] = a.v[at_row(a, sq, tok) * a.ldv + hcol + (tid & 63)];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int tok = min(key0 + kr + 16 * i, a.L - 1);
+        dst.v4[i] = *reinterpret_cast<const f32x4 *>(a.v + at_row(a, sq, tok) * a.ldv + hcol + c4 * 4);
+      }
+    }
+  };
   auto issue_stage = [&](int key0, int sq, int hcol) {
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int tok = min(key0 + kr + 16 * i, a.L - 1);
       const long row = at_row(a, sq, tok);
       rk[i] = *reinterpret_cast<const f32x4 *>(a.k + row * a.ldk + hcol + c4 * 4);
-      rv[i] = *reinterpret_cast<const f32x4 *>(a.v + row * a.ldv + hcol + c4 * 4);
     }
+    load_v(rv, key0, sq, hcol);
   };
   // K/V registers of one staged tile -> an LDS region (S3: K goes in as three bf16 planes, 8 bytes per thread, row and plane)
-  auto store_kv = [&](float *region, const f32x4 *k2, const f32x4 *v2) {
+  auto store_kv = [&](float *region, const f32x4 *k2, const VRegs &v2) {
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       if constexpr (S3) {
@@ -290,8 +321,21 @@ __global__ __launch_bounds__(256, (NBUF * UP >= 4 || (S3 && UP > 1)) ? 2 : 3) vo
         *reinterpret_cast<at_u32x2 *>(kb + 2 * AT_KT * AT_K3_ROWB) = at_u32x2{c0, c1};
       } else {
         *reinterpret_cast<f32x4 *>(region + (kr + 16 * i) * AT_LDK + c4 * 4) = k2[i];
+        *reinterpret_cast<f32x4 *>(region + KF + (kr + 16 * i) * AT_LDV + c4 * 4) = v2.v4[i];
       }
-      *reinterpret_cast<f32x4 *>(region + KF + (kr + 16 * i) * AT_LDV + c4 * 4) = v2[i];
+    }
+    if constexpr (S3) {   // V^T planes: row d = tid & 63, 16-byte slot = key octet (wave)
+      at_u32x4 p1, p2, p3;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        unsigned x1, x2, x3;
+        s3_split_pair(v2.v1[2 * j], v2.v1[2 * j + 1], x1, x2, x3);
+        p1[j] = x1, p2[j] = x2, p3[j] = x3;
+      }
+      unsigned char *vb = reinterpret_cast<unsigned char *>(region + KF) + (tid & 63) * AT_V3_ROWB + wave * 16;
+      *reinterpret_cast<at_u32x4 *>(vb) = p1;
+      *reinterpret_cast<at_u32x4 *>(vb + 64 * AT_V3_ROWB) = p2;
+      *reinterpret_cast<at_u32x4 *>(vb + 2 * 64 * AT_V3_ROWB) = p3;
     }
   };
   auto store_stage = [&](float *region) { store_kv(region, rk, rv); };
@@ -375,12 +419,45 @@ __global__ __launch_bounds__(256, (NBUF * UP >= 4 || (S3 && UP > 1)) ? 2 : 3) vo
 #pragma unroll
     for (int e = 0; e < 16; e++) o0[e] *= alpha, o1[e] *= alpha;
     // ---- O^T[d][q] += sum_key V[key][d] * P[q][key];  k-step e pairs key (e&3)+8*(e>>2)+4*lh ----
+    if constexpr (S3) {
+      // P (this lane's 16 values, in [0, 1]) -> three bf16 pieces; elements 8 G .. 8 G + 7 are k-slots (lh, 0..7) of group G
+      at_u32x4 pp[2][3];
 #pragma unroll
-    for (int e = 0; e < 16; e++) {
-      const int key = (e & 3) + 8 * (e >> 2) + 4 * lh;
-      const float v0 = sV[key * AT_LDV + lq], v1 = sV[key * AT_LDV + 32 + lq];
-      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[e], o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[e], o1, 0, 0, 0);
+      for (int G = 0; G < 2; G++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          unsigned x1, x2, x3;
+          s3_split_pair(s[8 * G + 2 * j], s[8 * G + 2 * j + 1], x1, x2, x3);
+          pp[G][0][j] = x1, pp[G][1][j] = x2, pp[G][2][j] = x3;
+        }
+      const unsigned char *vb = reinterpret_cast<const unsigned char *>(sV) + lq * AT_V3_ROWB + lh * 16;
+#pragma unroll
+      for (int G = 0; G < 2; G++) {
+        const at_bf16x8 p1 = __builtin_bit_cast(at_bf16x8, pp[G][0]), p2 = __builtin_bit_cast(at_bf16x8, pp[G][1]),
+                        p3 = __builtin_bit_cast(at_bf16x8, pp[G][2]);
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+          const unsigned char *vo = vb + o * 32 * AT_V3_ROWB + G * 32;
+          const at_bf16x8 v1 = *reinterpret_cast<const at_bf16x8 *>(vo);
+          const at_bf16x8 v2 = *reinterpret_cast<const at_bf16x8 *>(vo + 64 * AT_V3_ROWB);
+          const at_bf16x8 v3 = *reinterpret_cast<const at_bf16x8 *>(vo + 2 * 64 * AT_V3_ROWB);
+          f32x16 &t = o ? o1 : o0;
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v3, p1, t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, p3, t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v2, p2, t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v2, p1, t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, p2, t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, p1, t, 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int key = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const float v0 = sV[key * AT_LDV + lq], v1 = sV[key * AT_LDV + 32 + lq];
+        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[e], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[e], o1, 0, 0, 0);
+      }
     }
   };
 
@@ -415,15 +492,16 @@ __global__ __launch_bounds__(256, (NBUF * UP >= 4 || (S3 && UP > 1)) ? 2 : 3) vo
       __builtin_amdgcn_s_barrier();
     }
   } else {
-    f32x4 rk2[2], rv2[2];   // second unit's tile: both must be written between the two barriers
+    f32x4 rk2[2];           // second unit's tile: both must be written between the two barriers
+    VRegs rv2;
     auto issue_stage2 = [&](int key0) {
 #pragma unroll
       for (int i = 0; i < 2; i++) {
         const int tok = min(key0 + kr + 16 * i, a.L - 1);
         const long row = at_row(a, seqB, tok);
         rk2[i] = *reinterpret_cast<const f32x4 *>(a.k + row * a.ldk + hcB + c4 * 4);
-        rv2[i] = *reinterpret_cast<const f32x4 *>(a.v + row * a.ldv + hcB + c4 * 4);
       }
+      load_v(rv2, key0, seqB, hcB);
     };
     issue_stage(0, seqA, hcA);
     if (two) issue_stage2(0);
