@@ -443,7 +443,7 @@ extern "C" int sgic_split3_f32(const float *d_x, int ld, int rows, int cols, int
   return sgic::check_launch("split3_rows_kernel");
 }
 
-#define SGIC_SPLIT3_TILE_MODES 7
+#define SGIC_SPLIT3_TILE_MODES 9
 
 template <int WAVES_M, int WAVES_N, int BM, int BN, int NS, int KS = 1>
 static int s3_launch(const S3Args &g, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
@@ -491,7 +491,8 @@ static int s3_dispatch(const S3Args &g, const sgic_launch_opts *opts, hipStream_
     // modes 6 / 7 = modes 1 / 2 for the rows that fill WHOLE rounds of the 256 CUs + the 64x128 two-per-CU tiles for the rest,
     // as two launches (the first ends on a full round, so nothing idles at the seam): a last round of big tiles that covers a
     // fraction of the chip costs a whole tile time, the small tiles finish it in about half.  One profiler record spans both.
-    const int big = mode - 5, TM = 128, TN = big == 1 ? 256 : 128;
+    // modes 8 / 9: the same split with the 32x32 latency tiles (64-k stages, three workgroups per CU) for the remaining rows
+    const int big = mode >= 8 ? mode - 7 : mode - 5, tail = mode >= 8 ? 4 : 5, TM = 128, TN = big == 1 ? 256 : 128;
     const long tiles_n = (N + TN - 1) / TN, tiles_m = (M + TM - 1) / TM;
     const long m_full = (tiles_m * tiles_n / 256) * 256 / tiles_n;   // m-tiles inside whole rounds
     const long m_split = m_full * TM;
@@ -503,7 +504,7 @@ static int s3_dispatch(const S3Args &g, const sgic_launch_opts *opts, hipStream_
       g2.m_base = (int)m_split;
       int rc = s3_mode(g1, big, st, e0, nullptr);
       if (rc) return rc;
-      return s3_mode(g2, 5, st, nullptr, e1);
+      return s3_mode(g2, tail, st, nullptr, e1);
     }
     mode = big;
   }
@@ -517,7 +518,8 @@ static int s3_dispatch(const S3Args &g, const sgic_launch_opts *opts, hipStream_
 // K % 32 == 0.  opts->tile_mode: 0 = heuristic, 1 = 128x256, 2 = 128x128, 3 = 64x64, 4 = 32x32 tiles (the latency kernel for
 // under-filled launches: 4 waves of one 16x16 block each, a dependent chain of 6 MFMAs per 32 k), 5 = 64x128 tiles with two
 // workgroups per CU (finer rounds for grids that are not a multiple of the chip), 6 / 7 = 1 / 2 for the rows that fill whole rounds
-// of the chip + mode 5 for the remaining rows (two launches); bitwise identical results.
+// of the chip + mode 5 for the remaining rows (two launches), 8 / 9 = the same with mode 4 for the remaining rows; bitwise identical
+// results.
 extern "C" int sgic_gemm_split3_f32(const float *d_A, int lda, int a_seg, int a_seg_stride, uint16_t *d_Aplanes,
                                     const uint16_t *d_Wplanes, const float *d_bias, const float *d_R, int ldr, float *d_C,
                                     int ldc, uint16_t *d_Cplanes, int M, int N, int K, int act, int c_seg, int c_seg_stride,

@@ -309,7 +309,7 @@ def _pick_and_launch(key, launch, big_enough, restore=None, modes=None):
 # depend on (N, K) and on the operands' kinds, never on M, so single-image and batched requests stay bitwise identical.
 PRECISION = os.environ.get("SGIC_GEMM", "split3")
 assert PRECISION in ("f32", "split3"), f"SGIC_GEMM={PRECISION!r}: expected f32 or split3"
-SPLIT3_MODES = (1, 2, 3, 4, 5, 6, 7)
+SPLIT3_MODES = (1, 2, 3, 4, 5, 6, 7, 8, 9)
 _W3 = {}          # (data_ptr, N, K, ldw, version) -> (planes, w): the weight is pinned so its address cannot be reused
 _W3_BYTES = 0
 _W3_LIMIT = 24 << 30
