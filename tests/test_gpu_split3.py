@@ -224,3 +224,21 @@ def test_single_tile_latency(ops):
     recs = ops.profile_end()
     best = min(ms for _, ms, _ in recs)
     assert len(recs) == 4 and best < 0.010, f"64x64x512 split GEMM took {best * 1e3:.1f} us"
+
+
+@pytest.mark.parametrize("M,N,K", [(70, 201, 32), (33, 7, 64), (257, 130, 128), (1, 4, 96), (300, 64, 192)])
+def test_edge_shapes_every_mode(ops, M, N, K):
+    """one or two K stages (incl. a single 64-k stage of the latency tile), N not a multiple of 4 (narrow epilogue), M = 1"""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g)
+    bias = torch.randn(N, device="cuda", generator=g)
+    r = torch.randn(M, N, device="cuda", generator=g)
+    ref = a.double() @ w.double().T + bias.double() + r.double()
+    first = None
+    for tile in ops.SPLIT3_MODES:
+        out = ops.gemm(a, w, bias, residual=r, precision="split3", tile=tile)
+        torch.cuda.synchronize()
+        assert float((out.double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())), tile
+        first = out if first is None else first
+        assert torch.equal(out, first), tile
