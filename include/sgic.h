@@ -219,7 +219,9 @@ int sgic_l2norm_u8(const float *d_x, int ldx, int M, int D, float *d_unit, uint8
  *   d_Cplanes != NULL: the result is written as planes [3][M][N] (the next GEMM's A operand) instead of d_C.
  *   opts->tile_mode: 0 = heuristic, 1 = 128x256, 2 = 128x128, 3 = 64x64, 4 = 32x32 (the latency kernel for
  *   under-filled launches), 5 = 64x128 (two workgroups per CU) workgroup tiles, 6 / 7 = 1 / 2 for the rows that
- *   fill whole rounds of the 256 CUs + 5 for the remaining rows (two launches), 8 / 9 = the same with 4 for the remaining rows. */
+ *   fill whole rounds of the 256 CUs + 5 for the remaining rows (two launches), 8 / 9 = the same with 4 for the remaining rows,
+ *   10 / 11 = 1 / 2 as a persistent launch (one resident workgroup per CU walks the tile list), 12 / 13 = 8 / 9 with the
+ *   whole rounds walked persistently. */
 int sgic_split3_f32(const float *d_x, int ld, int rows, int cols, int seg, int seg_stride, uint16_t *d_planes,
                     sgic_stream_t stream);
 int sgic_gemm_split3_f32(const float *d_A, int lda, int a_seg, int a_seg_stride, uint16_t *d_Aplanes,

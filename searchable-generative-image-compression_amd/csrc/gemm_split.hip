@@ -99,10 +99,13 @@ struct S3Args {
 // hundred MFMA cycles and one workgroup per CU has nothing else to hide a ~2 us load behind).
 // KS = 32-k slices per LDS stage (rows of 64 KS bytes): 2 for the small tiles when K % 64 == 0 -- one barrier and one round of
 // exposed LDS latency per 64 k instead of per 32 k, which is what bounds a launch of one wave per SIMD.
-template <int WAVES_M, int WAVES_N, int BM, int BN, int NS, int KS>
+// PERSIST: gridDim.x resident workgroups (one per CU) walk the tile list; the next tile's first K stage is requested BEFORE the
+// current tile's epilogue, so the first-load latency of a tile hides behind the previous tile's stores.
+template <int WAVES_M, int WAVES_N, int BM, int BN, int NS, int KS, bool PERSIST>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (2 * 3 * 16 * (BM * WAVES_M + BN * WAVES_N) * 64 * KS <= 80 * 1024 && WAVES_M * WAVES_N == 8) ? 2 : 1)
 void gemm_split3_kernel(S3Args g) {
   static_assert(KS == 1 || KS == 2, "32-k slices per stage");
+  static_assert(!PERSIST || NS == 1, "the persistent walk is built on the one-register-set pipeline");
   constexpr int NT = 64 * WAVES_M * WAVES_N, TM = 16 * BM * WAVES_M, TN = 16 * BN * WAVES_N;
   constexpr int ROWB = 64 * KS, SL = 4 * KS;                                    // bytes / 16-byte slots per LDS row
   constexpr int CA = (TM * SL + NT - 1) / NT, CW = (TN * SL + NT - 1) / NT;     // 16-byte chunks per thread, plane and stage
@@ -113,22 +116,23 @@ void gemm_split3_kernel(S3Args g) {
 
   const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN, nwg = tiles_m * tiles_n;
   int m0, n0;
-  {   // XCD-aware bijective remap + grouped walk (8 m-tiles x all n-tiles, m fastest), as gemm.hip
-    int t = blockIdx.x;
+  auto locate = [&](int t) __attribute__((always_inline)) {   // XCD-aware bijective remap + grouped walk (8 m-tiles x all n-tiles, m fastest), as gemm.hip
     const int q = nwg >> 3, r = nwg & 7, xcd = t & 7, within = t >> 3;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
     const int per_group = 8 * tiles_n, group = t / per_group, first_m = group * 8, gsz = min(tiles_m - first_m, 8),
               in_group = t - group * per_group;
     m0 = (first_m + in_group % gsz) * TM;
     n0 = (in_group / gsz) * TN;
-  }
+  };
+  int tile = blockIdx.x;
+  locate(tile);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / WAVES_N) * (16 * BM), wn = (wave % WAVES_N) * (16 * BN);
   // LDS image of a stage: per plane, rows of 64 KS bytes unpadded; the 16-byte slot s of row r sits at slot s ^ swz(r):
   //   KS = 1: swz = f((r >> 2) & 3), f = (0, 2, 3, 1);   KS = 2: swz = (r >> 1) & 7
   // -- conflict-free for the ds_read_b128 lane groups {0-3,12-15,20-27}, ... of a fragment read (row = lane & 15,
   // slot = 4 slice + (lane >> 4)) and for ds_write_b128 (8 consecutive lanes = whole rows)
-  auto swz = [](int row) {
+  auto swz = [](int row) __attribute__((always_inline)) {
     if constexpr (KS == 1) {
       const int gq = (row >> 2) & 3;
       return (((gq ^ (gq >> 1)) & 1) << 1) | (gq >> 1);
@@ -141,21 +145,24 @@ void gemm_split3_kernel(S3Args g) {
   const int srow = tid / SL, sslot = tid % SL;
   const int sw = srow * ROWB + ((sslot ^ swz(srow)) * 16);
   const unsigned short *aptr[CA], *wptr[CW];
+  auto setup = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int i = 0; i < CA; i++) {
-    const int am = min(m0 + srow + i * (NT / SL), g.M - 1);
-    if (g.conv_C) {   // top-left pixel of the 3x3 patch in the halo buffer
-      const int hw = g.conv_H * g.conv_W, b = am / hw, r = am - b * hw, y = r / g.conv_W, x = r - y * g.conv_W;
-      aptr[i] = g.A + (((size_t)b * (g.conv_H + 2) + y) * (g.conv_W + 2) + x) * g.conv_C + sslot * 8;
-    } else {
-      aptr[i] = g.A + (size_t)am * g.K + sslot * 8;
+    for (int i = 0; i < CA; i++) {
+      const int am = min(m0 + srow + i * (NT / SL), g.M - 1);
+      if (g.conv_C) {   // top-left pixel of the 3x3 patch in the halo buffer
+        const int hw = g.conv_H * g.conv_W, b = am / hw, r = am - b * hw, y = r / g.conv_W, x = r - y * g.conv_W;
+        aptr[i] = g.A + (((size_t)b * (g.conv_H + 2) + y) * (g.conv_W + 2) + x) * g.conv_C + sslot * 8;
+      } else {
+        aptr[i] = g.A + (size_t)am * g.K + sslot * 8;
+      }
     }
-  }
 #pragma unroll
-  for (int i = 0; i < CW; i++) wptr[i] = g.W + (size_t)min(n0 + srow + i * (NT / SL), g.N - 1) * g.K + sslot * 8;
+    for (int i = 0; i < CW; i++) wptr[i] = g.W + (size_t)min(n0 + srow + i * (NT / SL), g.N - 1) * g.K + sslot * 8;
+  };
+  setup();
   const bool a_on = CA * NT == TM * SL || srow < TM, w_on = CW * NT == TN * SL || srow < TN;   // tiles smaller than a pass
   u32x4 ra[NS][3][CA], rw[NS][3][CW];
-  auto issue = [&](int k0, auto set_c) {
+  auto issue = [&](int k0, auto set_c) __attribute__((always_inline)) {
     constexpr int S = decltype(set_c)::value;
     int ka = k0;
     if (g.conv_C) {   // wave-uniform: the tap this K stage belongs to (conv_C % (32 KS) == 0: a stage never straddles a tap)
@@ -170,7 +177,7 @@ void gemm_split3_kernel(S3Args g) {
       for (int i = 0; i < CW; i++) rw[S][p][i] = *reinterpret_cast<const u32x4 *>(wptr[i] + p * g.w_plane + k0);
     }
   };
-  auto store = [&](int buf, auto set_c) {
+  auto store = [&](int buf, auto set_c) __attribute__((always_inline)) {
     constexpr int S = decltype(set_c)::value;
     unsigned char *base = smem + buf * STAGE + sw;
 #pragma unroll
@@ -186,10 +193,6 @@ void gemm_split3_kernel(S3Args g) {
     }
   };
   f32x4 acc[BM][BN];
-#pragma unroll
-  for (int i = 0; i < BM; i++)
-#pragma unroll
-    for (int j = 0; j < BN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int l16 = lane & 15, lq = lane >> 4;
   // fragment address of (row base + l16, slot 4 slice + lq): block bases are multiples of 16 rows, so the swizzle term is the
   // lane's own
@@ -198,18 +201,18 @@ void gemm_split3_kernel(S3Args g) {
   for (int ks = 0; ks < KS; ks++) foff[ks] = l16 * ROWB + (((4 * ks + lq) ^ swz(l16)) * 16);
   const int abase = wm * ROWB, bbase = 3 * APLANE + wn * ROWB;
   bf16x8 wf[3][BN], af[2][3];
-  auto read_w = [&](int buf, int j, int ks) {
+  auto read_w = [&](int buf, int j, int ks) __attribute__((always_inline)) {
     const unsigned char *base = smem + buf * STAGE + bbase + j * 16 * ROWB + foff[ks];
 #pragma unroll
     for (int p = 0; p < 3; p++) wf[p][j] = *reinterpret_cast<const bf16x8 *>(base + p * WPLANE);
   };
-  auto read_a = [&](int buf, int i, int set, int ks) {
+  auto read_a = [&](int buf, int i, int set, int ks) __attribute__((always_inline)) {
     const unsigned char *base = smem + buf * STAGE + abase + i * 16 * ROWB + foff[ks];
 #pragma unroll
     for (int p = 0; p < 3; p++) af[set][p] = *reinterpret_cast<const bf16x8 *>(base + p * APLANE);
   };
   // one 16 x 16 block over a 32-k slice: the six terms, smallest first -- THE order of the arithmetic (see the header)
-  auto block = [&](int i, int j, int set) {
+  auto block = [&](int i, int j, int set) __attribute__((always_inline)) {
     f32x4 c = acc[i][j];
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][j], af[set][2], c, 0, 0, 0);   // a3 w1
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2][j], af[set][0], c, 0, 0, 0);   // a1 w3
@@ -221,27 +224,35 @@ void gemm_split3_kernel(S3Args g) {
   };
   constexpr int BKS = 32 * KS;
   const int nk = g.K / BKS;
-  issue(0, IntC<0>{});
-  store(0, IntC<0>{});
-  if constexpr (NS == 1) {
-    if (nk > 1) issue(BKS, IntC<0>{});
-  } else {
-    // stages 1 .. NS into sets 1 .. NS-1, 0 (stage j lives in set j % NS; set 0 was just stored)
-    s3_for<NS>([&](auto u_c) {
-      constexpr int J = decltype(u_c)::value + 1;
-      if (J < nk) issue(J * BKS, IntC<J % NS>{});
-    });
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  // prologue of the rotating schedule: Whi and A row 0 of slice 0
+  // start of a tile: its first stage is already in flight (issued here for the first tile, before the previous tile's epilogue
+  // for the following ones)
+  auto tile_prologue = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int j = BN - HB; j < BN; j++) read_w(0, j, 0);
-  read_a(0, 0, 0, 0);
+    for (int i = 0; i < BM; i++)
+#pragma unroll
+      for (int j = 0; j < BN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    store(0, IntC<0>{});
+    if constexpr (NS == 1) {
+      if (nk > 1) issue(BKS, IntC<0>{});
+    } else {
+      // stages 1 .. NS into sets 1 .. NS-1, 0 (stage j lives in set j % NS; set 0 was just stored)
+      s3_for<NS>([&](auto u_c) __attribute__((always_inline)) {
+        constexpr int J = decltype(u_c)::value + 1;
+        if (J < nk) issue(J * BKS, IntC<J % NS>{});
+      });
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // prologue of the rotating schedule: Whi and A row 0 of slice 0
+#pragma unroll
+    for (int j = BN - HB; j < BN; j++) read_w(0, j, 0);
+    read_a(0, 0, 0, 0);
+  };
+  issue(0, IntC<0>{});
   // MFMA part of ONE 32-k slice (index KSI of its stage).  The slice's first fragments (Whi, A row 0) were read during the
   // previous slice's tail; its own tail reads the next slice's: slice KSI + 1 of the same stage, or -- behind the stage's one
   // barrier -- slice 0 of the other stage (`more`: a next stage exists).
-  auto compute = [&](int cur, auto ks_c, bool more) {
+  auto compute = [&](int cur, auto ks_c, bool more) __attribute__((always_inline)) {
     constexpr int KSI = decltype(ks_c)::value;
     constexpr bool LAST = KSI == KS - 1;
     const int nxt = cur ^ 1;
@@ -289,100 +300,140 @@ void gemm_split3_kernel(S3Args g) {
     }
   };
   static_assert((BM == 1 && BN == 1) || (BM % 2) == 0, "A row 0 of the next slice must land in set 0, free at that point");
-  auto stage_mfma = [&](int cur, bool more) {
-    s3_for<KS>([&](auto ks_c) { compute(cur, ks_c, more); });
-  };
-  if constexpr (NS == 1) {
-    auto stage = [&](int kt, auto store_c, auto issue_c) {
-      constexpr bool ST = decltype(store_c)::value, IS = decltype(issue_c)::value;
-      if constexpr (ST) store((kt & 1) ^ 1, IntC<0>{});
-      if constexpr (IS) issue((kt + 2) * BKS, IntC<0>{});
-      stage_mfma(kt & 1, ST);
+  auto tile_mainloop = [&]() __attribute__((always_inline)) {
+    auto stage_mfma = [&](int cur, bool more) __attribute__((always_inline)) {
+      s3_for<KS>([&](auto ks_c) __attribute__((always_inline)) { compute(cur, ks_c, more); });
     };
-    using T = std::true_type;
-    using F = std::false_type;
-    int kt = 0;
-    for (; kt + 2 < nk; ++kt) stage(kt, T{}, T{});
-    if (kt + 1 < nk) {
-      stage(kt, T{}, F{});
-      ++kt;
-    }
-    stage(kt, F{}, F{});
-  } else {
-    for (int base = 0; base < nk; base += NS) {
-      s3_for<NS>([&](auto u_c) {
-        constexpr int U = decltype(u_c)::value;
-        const int kt = base + U;              // base % NS == 0: stage kt + 1 lives in set (U + 1) % NS
-        if (kt < nk) {                        // uniform
-          const bool more = kt + 1 < nk;
-          if (more) {
-            store((kt & 1) ^ 1, IntC<(U + 1) % NS>{});
-            if (kt + 1 + NS < nk) issue((kt + 1 + NS) * BKS, IntC<(U + 1) % NS>{});
+    if constexpr (NS == 1) {
+      auto stage = [&](int kt, auto store_c, auto issue_c) __attribute__((always_inline)) {
+        constexpr bool ST = decltype(store_c)::value, IS = decltype(issue_c)::value;
+        if constexpr (ST) store((kt & 1) ^ 1, IntC<0>{});
+        if constexpr (IS) issue((kt + 2) * BKS, IntC<0>{});
+        stage_mfma(kt & 1, ST);
+      };
+      using T = std::true_type;
+      using F = std::false_type;
+      int kt = 0;
+      for (; kt + 2 < nk; ++kt) stage(kt, T{}, T{});
+      if (kt + 1 < nk) {
+        stage(kt, T{}, F{});
+        ++kt;
+      }
+      stage(kt, F{}, F{});
+    } else {
+      for (int base = 0; base < nk; base += NS) {
+        s3_for<NS>([&](auto u_c) __attribute__((always_inline)) {
+          constexpr int U = decltype(u_c)::value;
+          const int kt = base + U;              // base % NS == 0: stage kt + 1 lives in set (U + 1) % NS
+          if (kt < nk) {                        // uniform
+            const bool more = kt + 1 < nk;
+            if (more) {
+              store((kt & 1) ^ 1, IntC<(U + 1) % NS>{});
+              if (kt + 1 + NS < nk) issue((kt + 1 + NS) * BKS, IntC<(U + 1) % NS>{});
+            }
+            stage_mfma(kt & 1, more);
           }
-          stage_mfma(kt & 1, more);
-        }
-      });
+        });
+      }
     }
-  }
+  };
 
-  // ---- epilogue: the accumulators hold C[m = block row base + l16][n = block column base + 4 lq .. + 3].  bias -> activation
-  // -> residual, as gemm.hip.  Wide path: the wave re-distributes its tile through its own LDS slice (free after the last
-  // barrier; row stride + 4 floats: conflict-free ds_write_b128) so that a store instruction writes whole row segments
-  // (16 BN floats per row), as float4 or -- when the consumer is the next GEMM -- directly as bf16x3 planes.
-  if (g.vec_epilogue) {
-    constexpr int RM = 16 * BM, CN = 16 * BN, LDW = CN + 4, LPR = CN / 4, RPI = 64 / LPR, NIT = RM / RPI;
-    float *ep = reinterpret_cast<float *>(smem) + wave * (RM * LDW);
-#pragma unroll
-    for (int i = 0; i < BM; i++)
-#pragma unroll
-      for (int j = 0; j < BN; j++) *reinterpret_cast<f32x4 *>(ep + (i * 16 + l16) * LDW + j * 16 + 4 * lq) = acc[i][j];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
-    const int n = n0 + wn + c4;
-    const bool colok = n < g.N;
-    const int nc = colok ? n : 0;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (g.bias && colok) bv = *reinterpret_cast<const f32x4 *>(g.bias + n);
-    auto run = [&](auto act_c, auto res_c, auto pl_c) {
-      constexpr int ACT = decltype(act_c)::value;
-      constexpr bool HASR = decltype(res_c)::value != 0, PLANES = decltype(pl_c)::value != 0;
-      constexpr int EB = NIT < 8 ? NIT : 8;    // rows in flight between the LDS read / residual load and the store
-#pragma unroll
-      for (int b = 0; b < NIT; b += EB) {
-        f32x4 cv[EB], rv[EB];
-#pragma unroll
-        for (int q = 0; q < EB; ++q) {
-          const int rr = (b + q) * RPI + r0;
-          cv[q] = *reinterpret_cast<const f32x4 *>(ep + rr * LDW + c4);
-          if constexpr (HASR) rv[q] = *reinterpret_cast<const f32x4 *>(g.R + (size_t)(min(m0 + wm + rr, g.M - 1) + g.m_base) * g.ldr + nc);
+  auto tile_epilogue = [&](int em0, int en0) __attribute__((always_inline)) {
+    // ---- epilogue: the accumulators hold C[m = block row base + l16][n = block column base + 4 lq .. + 3].  bias -> activation
+    // -> residual, as gemm.hip.  Wide path: the wave re-distributes its tile through its own LDS slice (free after the last
+    // barrier; row stride + 4 floats: conflict-free ds_write_b128) so that a store instruction writes whole row segments
+    // (16 BN floats per row), as float4 or -- when the consumer is the next GEMM -- directly as bf16x3 planes.
+    if (g.vec_epilogue) {
+      constexpr int RM = 16 * BM, CN = 16 * BN, LDW = CN + 4, LPR = CN / 4, RPI = 64 / LPR, NIT = RM / RPI;
+      float *ep = reinterpret_cast<float *>(smem) + wave * (RM * LDW);
+  #pragma unroll
+      for (int i = 0; i < BM; i++)
+  #pragma unroll
+        for (int j = 0; j < BN; j++) *reinterpret_cast<f32x4 *>(ep + (i * 16 + l16) * LDW + j * 16 + 4 * lq) = acc[i][j];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
+      const int n = en0 + wn + c4;
+      const bool colok = n < g.N;
+      const int nc = colok ? n : 0;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (g.bias && colok) bv = *reinterpret_cast<const f32x4 *>(g.bias + n);
+      auto run = [&](auto act_c, auto res_c, auto pl_c) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(act_c)::value;
+        constexpr bool HASR = decltype(res_c)::value != 0, PLANES = decltype(pl_c)::value != 0;
+        constexpr int EB = NIT < 8 ? NIT : 8;    // rows in flight between the LDS read / residual load and the store
+  #pragma unroll
+        for (int b = 0; b < NIT; b += EB) {
+          f32x4 cv[EB], rv[EB];
+  #pragma unroll
+          for (int q = 0; q < EB; ++q) {
+            const int rr = (b + q) * RPI + r0;
+            cv[q] = *reinterpret_cast<const f32x4 *>(ep + rr * LDW + c4);
+            if constexpr (HASR) rv[q] = *reinterpret_cast<const f32x4 *>(g.R + (size_t)(min(em0 + wm + rr, g.M - 1) + g.m_base) * g.ldr + nc);
+          }
+  #pragma unroll
+          for (int q = 0; q < EB; ++q) {
+            const int m = em0 + wm + (b + q) * RPI + r0;
+            f32x4 v = cv[q];
+  #pragma unroll
+            for (int t = 0; t < 4; t++) v[t] = apply_act_c<ACT>(v[t] + bv[t]);
+            if constexpr (HASR) v += rv[q];
+            if (colok && m < g.M) {
+              if constexpr (PLANES) {
+                s3_store4(g.Cp, g.c_plane, (size_t)(m + g.m_base) * g.N + n, v);
+              } else {
+                const int mm = m + g.m_base;
+                const size_t crow = g.c_seg ? (size_t)(mm / g.c_seg) * g.c_seg_stride + (mm % g.c_seg) : (size_t)mm;
+                *reinterpret_cast<f32x4 *>(g.C + crow * g.ldc + n) = v;
+              }
+            }
+          }
         }
-#pragma unroll
-        for (int q = 0; q < EB; ++q) {
-          const int m = m0 + wm + (b + q) * RPI + r0;
-          f32x4 v = cv[q];
-#pragma unroll
-          for (int t = 0; t < 4; t++) v[t] = apply_act_c<ACT>(v[t] + bv[t]);
-          if constexpr (HASR) v += rv[q];
-          if (colok && m < g.M) {
-            if constexpr (PLANES) {
-              s3_store4(g.Cp, g.c_plane, (size_t)(m + g.m_base) * g.N + n, v);
-            } else {
-              const int mm = m + g.m_base;
-              const size_t crow = g.c_seg ? (size_t)(mm / g.c_seg) * g.c_seg_stride + (mm % g.c_seg) : (size_t)mm;
-              *reinterpret_cast<f32x4 *>(g.C + crow * g.ldc + n) = v;
+      };
+      auto run_act = [&](auto act_c) __attribute__((always_inline)) {
+        if (g.Cp) {
+          if (g.R) run(act_c, IntC<1>{}, IntC<1>{});
+          else run(act_c, IntC<0>{}, IntC<1>{});
+        } else {
+          if (g.R) run(act_c, IntC<1>{}, IntC<0>{});
+          else run(act_c, IntC<0>{}, IntC<0>{});
+        }
+      };
+      switch (g.act) {
+        case ACT_GELU: run_act(IntC<ACT_GELU>{}); break;
+        case ACT_SILU: run_act(IntC<ACT_SILU>{}); break;
+        case ACT_TANH: run_act(IntC<ACT_TANH>{}); break;
+        case ACT_LRELU: run_act(IntC<ACT_LRELU>{}); break;
+        default: run_act(IntC<ACT_NONE>{}); break;
+      }
+      return;
+    }
+    // narrow path (N or the leading dimensions not float4-addressable): one dword at a time from the accumulators
+    auto run = [&](auto act_c, auto res_c) __attribute__((always_inline)) {
+      constexpr int ACT = decltype(act_c)::value;
+      constexpr bool HASR = decltype(res_c)::value != 0;
+  #pragma unroll
+      for (int j = 0; j < BN; j++) {
+        const int n = en0 + wn + j * 16 + 4 * lq;
+  #pragma unroll
+        for (int i = 0; i < BM; i++) {
+          const int m = em0 + wm + i * 16 + l16;
+          if (m >= g.M) continue;
+          const int mm = m + g.m_base;
+          const size_t crow = g.c_seg ? (size_t)(mm / g.c_seg) * g.c_seg_stride + (mm % g.c_seg) : (size_t)mm;
+  #pragma unroll
+          for (int t = 0; t < 4; t++) {
+            if (n + t < g.N) {
+              float o = apply_act_c<ACT>(acc[i][j][t] + (g.bias ? g.bias[n + t] : 0.f));
+              if constexpr (HASR) o += g.R[(size_t)mm * g.ldr + n + t];
+              g.C[crow * g.ldc + n + t] = o;
             }
           }
         }
       }
     };
-    auto run_act = [&](auto act_c) {
-      if (g.Cp) {
-        if (g.R) run(act_c, IntC<1>{}, IntC<1>{});
-        else run(act_c, IntC<0>{}, IntC<1>{});
-      } else {
-        if (g.R) run(act_c, IntC<1>{}, IntC<0>{});
-        else run(act_c, IntC<0>{}, IntC<0>{});
-      }
+    auto run_act = [&](auto act_c) __attribute__((always_inline)) {
+      if (g.R) run(act_c, IntC<1>{});
+      else run(act_c, IntC<0>{});
     };
     switch (g.act) {
       case ACT_GELU: run_act(IntC<ACT_GELU>{}); break;
@@ -391,42 +442,26 @@ void gemm_split3_kernel(S3Args g) {
       case ACT_LRELU: run_act(IntC<ACT_LRELU>{}); break;
       default: run_act(IntC<ACT_NONE>{}); break;
     }
-    return;
-  }
-  // narrow path (N or the leading dimensions not float4-addressable): one dword at a time from the accumulators
-  auto run = [&](auto act_c, auto res_c) {
-    constexpr int ACT = decltype(act_c)::value;
-    constexpr bool HASR = decltype(res_c)::value != 0;
-#pragma unroll
-    for (int j = 0; j < BN; j++) {
-      const int n = n0 + wn + j * 16 + 4 * lq;
-#pragma unroll
-      for (int i = 0; i < BM; i++) {
-        const int m = m0 + wm + i * 16 + l16;
-        if (m >= g.M) continue;
-        const int mm = m + g.m_base;
-        const size_t crow = g.c_seg ? (size_t)(mm / g.c_seg) * g.c_seg_stride + (mm % g.c_seg) : (size_t)mm;
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-          if (n + t < g.N) {
-            float o = apply_act_c<ACT>(acc[i][j][t] + (g.bias ? g.bias[n + t] : 0.f));
-            if constexpr (HASR) o += g.R[(size_t)mm * g.ldr + n + t];
-            g.C[crow * g.ldc + n + t] = o;
-          }
-        }
+  };
+
+  for (;;) {
+    tile_prologue();
+    tile_mainloop();
+    const int em0 = m0, en0 = n0;   // the tile being finished
+    bool more_tiles = false;
+    if constexpr (PERSIST) {
+      tile += gridDim.x;
+      more_tiles = tile < nwg;
+      if (more_tiles) {   // the next tile's first stage flies during the epilogue below
+        locate(tile);
+        setup();
+        issue(0, IntC<0>{});
       }
     }
-  };
-  auto run_act = [&](auto act_c) {
-    if (g.R) run(act_c, IntC<1>{});
-    else run(act_c, IntC<0>{});
-  };
-  switch (g.act) {
-    case ACT_GELU: run_act(IntC<ACT_GELU>{}); break;
-    case ACT_SILU: run_act(IntC<ACT_SILU>{}); break;
-    case ACT_TANH: run_act(IntC<ACT_TANH>{}); break;
-    case ACT_LRELU: run_act(IntC<ACT_LRELU>{}); break;
-    default: run_act(IntC<ACT_NONE>{}); break;
+    tile_epilogue(em0, en0);
+    if (!more_tiles) break;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // every wave is done with its epilogue slice before the staging buffers are refilled
   }
 }
 
@@ -443,19 +478,20 @@ extern "C" int sgic_split3_f32(const float *d_x, int ld, int rows, int cols, int
   return sgic::check_launch("split3_rows_kernel");
 }
 
-#define SGIC_SPLIT3_TILE_MODES 9
+#define SGIC_SPLIT3_TILE_MODES 13
 
-template <int WAVES_M, int WAVES_N, int BM, int BN, int NS, int KS = 1>
+template <int WAVES_M, int WAVES_N, int BM, int BN, int NS, int KS = 1, bool PERSIST = false>
 static int s3_launch(const S3Args &g, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
   constexpr int NT = 64 * WAVES_M * WAVES_N, TM = 16 * BM * WAVES_M, TN = 16 * BN * WAVES_N;
   constexpr int LDS = 2 * 3 * (TM + TN) * 64 * KS;
   static bool attr_set = false;   // idempotent: a race sets the same value twice
-  auto kernel = gemm_split3_kernel<WAVES_M, WAVES_N, BM, BN, NS, KS>;
+  auto kernel = gemm_split3_kernel<WAVES_M, WAVES_N, BM, BN, NS, KS, PERSIST>;
   if (!attr_set) {
     SGIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
-  const dim3 grid((unsigned)(((g.M + TM - 1) / TM) * ((g.N + TN - 1) / TN)));
+  unsigned ntiles = (unsigned)(((g.M + TM - 1) / TM) * ((g.N + TN - 1) / TN));
+  const dim3 grid(PERSIST ? (ntiles < 256u ? ntiles : 256u) : ntiles);   // persistent: one resident workgroup per CU
   if (ev_start || ev_stop) {
     hipExtLaunchKernelGGL(kernel, grid, dim3(NT), LDS, st, ev_start, ev_stop, 0, g);
   } else {
@@ -471,6 +507,8 @@ static int s3_mode(const S3Args &g, int mode, hipStream_t st, hipEvent_t e0, hip
     // the 32x32 latency tile: 64-k stages when K allows (and, for a convolution, a stage stays inside one tap)
     case 3: return s3_launch<2, 2, 2, 2, 4>(g, st, e0, e1);   // (64-k stages measured no better for the 64x64 tile)
     case 4: return (g.K % 64 == 0 && g.conv_C % 64 == 0) ? s3_launch<2, 2, 1, 1, 3, 2>(g, st, e0, e1) : s3_launch<2, 2, 1, 1, 6>(g, st, e0, e1);
+    case 10: return s3_launch<2, 4, 4, 4, 1, 1, true>(g, st, e0, e1);
+    case 11: return s3_launch<2, 4, 4, 2, 1, 1, true>(g, st, e0, e1);
     default: return s3_launch<2, 4, 2, 2, 1>(g, st, e0, e1);
   }
 }
@@ -487,12 +525,14 @@ static int s3_dispatch(const S3Args &g, const sgic_launch_opts *opts, hipStream_
   }
   const auto *evp = prof_next(opts);
   hipEvent_t e0 = evp ? evp->first : nullptr, e1 = evp ? evp->second : nullptr;
-  if (mode >= 6) {
+  if ((mode >= 6 && mode <= 9) || mode >= 12) {
     // modes 6 / 7 = modes 1 / 2 for the rows that fill WHOLE rounds of the 256 CUs + the 64x128 two-per-CU tiles for the rest,
     // as two launches (the first ends on a full round, so nothing idles at the seam): a last round of big tiles that covers a
     // fraction of the chip costs a whole tile time, the small tiles finish it in about half.  One profiler record spans both.
     // modes 8 / 9: the same split with the 32x32 latency tiles (64-k stages, three workgroups per CU) for the remaining rows
-    const int big = mode >= 8 ? mode - 7 : mode - 5, tail = mode >= 8 ? 4 : 5, TM = 128, TN = big == 1 ? 256 : 128;
+    // modes 12 / 13: as 8 / 9 with the whole rounds walked by the persistent launch (10 / 11)
+    const int big = mode >= 12 ? mode - 11 : (mode >= 8 ? mode - 7 : mode - 5), tail = mode >= 8 ? 4 : 5, TM = 128, TN = big == 1 ? 256 : 128;
+    const int big_mode = mode >= 12 ? big + 9 : big;
     const long tiles_n = (N + TN - 1) / TN, tiles_m = (M + TM - 1) / TM;
     const long m_full = (tiles_m * tiles_n / 256) * 256 / tiles_n;   // m-tiles inside whole rounds
     const long m_split = m_full * TM;
@@ -502,11 +542,11 @@ static int s3_dispatch(const S3Args &g, const sgic_launch_opts *opts, hipStream_
       g2.M = M - (int)m_split;
       g2.A += m_split * K;          // the planes keep their stride (a_plane); C / R / Cp rows are addressed through m_base
       g2.m_base = (int)m_split;
-      int rc = s3_mode(g1, big, st, e0, nullptr);
+      int rc = s3_mode(g1, big_mode, st, e0, nullptr);
       if (rc) return rc;
       return s3_mode(g2, tail, st, nullptr, e1);
     }
-    mode = big;
+    mode = big_mode;
   }
   return s3_mode(g, mode, st, e0, e1);
 }
@@ -518,8 +558,9 @@ static int s3_dispatch(const S3Args &g, const sgic_launch_opts *opts, hipStream_
 // K % 32 == 0.  opts->tile_mode: 0 = heuristic, 1 = 128x256, 2 = 128x128, 3 = 64x64, 4 = 32x32 tiles (the latency kernel for
 // under-filled launches: 4 waves of one 16x16 block each, a dependent chain of 6 MFMAs per 32 k), 5 = 64x128 tiles with two
 // workgroups per CU (finer rounds for grids that are not a multiple of the chip), 6 / 7 = 1 / 2 for the rows that fill whole rounds
-// of the chip + mode 5 for the remaining rows (two launches), 8 / 9 = the same with mode 4 for the remaining rows; bitwise identical
-// results.
+// of the chip + mode 5 for the remaining rows (two launches), 8 / 9 = the same with mode 4 for the remaining rows, 10 / 11 = 1 / 2
+// as a persistent launch (256 resident workgroups walk the tiles, the next tile's first loads fly during the epilogue), 12 / 13 =
+// 8 / 9 with the whole rounds walked persistently; bitwise identical results.
 extern "C" int sgic_gemm_split3_f32(const float *d_A, int lda, int a_seg, int a_seg_stride, uint16_t *d_Aplanes,
                                     const uint16_t *d_Wplanes, const float *d_bias, const float *d_R, int ldr, float *d_C,
                                     int ldc, uint16_t *d_Cplanes, int M, int N, int K, int act, int c_seg, int c_seg_stride,

@@ -59,7 +59,7 @@ def test_bitwise_independent_of_tile_and_batch(ops):
     a = torch.randn(M, K, device="cuda", generator=g)
     w = torch.randn(N, K, device="cuda", generator=g) * 0.05
     bias = torch.randn(N, device="cuda", generator=g)
-    outs = [ops.gemm(a, w, bias, act=ops.ACT_GELU, precision="split3", tile=t) for t in (1, 2, 3, 4, 5, 6, 7, 8, 9)]
+    outs = [ops.gemm(a, w, bias, act=ops.ACT_GELU, precision="split3", tile=t) for t in ops.SPLIT3_MODES]
     torch.cuda.synchronize()
     assert all(torch.equal(outs[0], o) for o in outs[1:])
     # a single "image" (rows 289..578) computed alone == the same rows inside the batch
@@ -192,7 +192,7 @@ def test_split_launch_modes_with_row_map_residual_and_planes(ops):
     bias = torch.randn(N, device="cuda", generator=g)
     r = torch.randn(M, N, device="cuda", generator=g)
     ref = {}
-    for tile in (1, 6, 7, 8, 9):
+    for tile in (1, 6, 7, 8, 9, 10, 11, 12, 13):
         out = torch.zeros(n * L, N, device="cuda")
         ops.gemm(a, w, bias, out=out, M=M, c_seg=(Lt, L), precision="split3", tile=tile)
         y = ops.gemm(a, w, bias, residual=r, act=ops.ACT_SILU, precision="split3", tile=tile)
@@ -204,7 +204,7 @@ def test_split_launch_modes_with_row_map_residual_and_planes(ops):
             ops.set_precision(old)
         torch.cuda.synchronize()
         ref[tile] = (out.clone(), y.clone(), pl.t.clone())
-    for tile in (6, 7, 8, 9):
+    for tile in (6, 7, 8, 9, 10, 11, 12, 13):
         assert all(torch.equal(p, q) for p, q in zip(ref[1], ref[tile])), tile
     o3 = ref[1][0].reshape(n, L, N)
     want = (a.double() @ w.double().T + bias.double()).reshape(n, Lt, N)

@@ -11,7 +11,7 @@ from sgic_amd import ops  # noqa: E402
 
 SHAPES = [(9248, 1024, 4096, 1, 0), (9248, 4096, 1024, 0, 1), (9248, 3072, 1024, 0, 0), (17440, 768, 3072, 1, 0), (17440, 3072, 768, 0, 1),
           (8192, 768, 3072, 1, 0), (9248, 1024, 1024, 1, 0), (8192, 2304, 768, 0, 0), (17440, 2304, 768, 0, 0)]
-MODES = (1, 2, 5, 6, 7, 8, 9)
+MODES = (1, 2, 6, 8, 9, 10, 11, 12, 13)
 
 
 def timed(fn, reps=8):

@@ -20,10 +20,10 @@ def dispatches(rec):
     """kernel dispatches behind one profile record: the split GEMM's modes 6 / 7 are two launches when the grid has whole rounds
     of the 256 CUs plus a tail (csrc/gemm_split.hip: s3_dispatch)"""
     key, mode = rec[0], (rec[3] if len(rec) > 3 else None)
-    if not is_s3(key) or mode not in (6, 7, 8, 9):
+    if not is_s3(key) or mode not in (6, 7, 8, 9, 12, 13):
         return 1
     M, N = key[0], key[1]
-    tn = 256 if mode in (6, 8) else 128
+    tn = 256 if mode in (6, 8, 12) else 128
     tiles_n, tiles_m = (N + tn - 1) // tn, (M + 127) // 128
     m_full = (tiles_m * tiles_n // 256) * 256 // tiles_n
     return 2 if (m_full > 0 and m_full * 128 < M) else 1
