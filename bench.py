@@ -493,6 +493,18 @@ def main():
                 "ms_per_step": round(fdt / args.secondary_steps * 1e3, 3),
                 "roofline": roofline_block(fprof, ops, dev, fdt, args.secondary_steps, gflop * 1e9 * B, "round2_pmc_f32_gemm_summary.json",
                                            "round2_pmc_f32_gemm_by_shape.json")}
+        if world == 1 and not args.small:
+            # live check of the claim behind `arithmetic`: rms error of a K = 4096 GEMM against an fp64 product, split GEMM vs the
+            # exact-fp32 MFMA GEMM on the same operands (measurement only: the fp64 product is a torch matmul, not the product path)
+            gg = torch.Generator(device=dev).manual_seed(7)
+            ta = torch.randn(512, 4096, device=dev, generator=gg)
+            tw = torch.randn(512, 4096, device=dev, generator=gg) * 0.03
+            ref = ta.double() @ tw.double().T
+            rms = float(ref.pow(2).mean().sqrt())
+            e3 = float((ops.gemm(ta, tw, precision="split3").double() - ref).pow(2).mean().sqrt()) / rms
+            e1 = float((ops.gemm(ta, tw, precision="f32").double() - ref).pow(2).mean().sqrt()) / rms
+            res["arithmetic_check"] = {"what": "rms error / rms(C) of a 512x512x4096 GEMM vs an fp64 product, same operands",
+                                       "split3_bf16x3": float(f"{e3:.3e}"), "fp32_mfma_chain": float(f"{e1:.3e}")}
         if world == 1 and not args.no_cpu_baseline and not args.small and not dec_primary:
             res["cpu_baseline"] = cpu_baseline(sd, clip_sd, cfg, clip_cfg)
         print(json.dumps(res), flush=True)
