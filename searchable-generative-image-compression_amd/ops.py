@@ -101,6 +101,9 @@ def _remember(key, mode, dirty=True):
     _DIRTY = _DIRTY or dirty
 
 
+_MAX_MODE = {"gemm": 15, "conv3x3": 15, "gemm3": 13, "conv3": 13, "attn": 6, "attn3": 6}   # per kind of key
+
+
 def _load_tile_cache():
     for path in (_INTREE_CACHE, _user_cache_path()):
         try:
@@ -110,8 +113,15 @@ def _load_tile_cache():
             continue
         for k, mode in d.get("picks", {}).items():
             parts = k.split("|")
-            key = (parts[0],) + tuple(int(x) for x in parts[1:])
-            _remember(key, int(mode), dirty=False)
+            try:
+                key = (parts[0],) + tuple(int(x) for x in parts[1:])
+                mode = int(mode)
+            except ValueError:
+                continue
+            # a cache written by another build may hold modes this library does not have: such a pick is dropped (re-raced)
+            if not 0 <= mode <= _MAX_MODE.get(parts[0], -1):
+                continue
+            _remember(key, mode, dirty=False)
 
 
 def save_tile_cache(path=None):

@@ -78,3 +78,16 @@ def test_tile_of_reads_profile_keys(ops):
     assert ops.tile_of((9248, 4096, 1024, False, 1)) == 12
     assert ops.tile_of(("batched", 32, 256, 256, 64, False, 0)) == 0
     assert ops.tile_of((1, 2, 3, False, 0)) is None
+
+
+def test_picks_of_another_build_are_dropped(ops, tmp_path):
+    """a user cache holding a launch mode this library does not have (written by a newer build) must not reach the C ABI"""
+    p = tmp_path / "cache.json"
+    p.write_text(json.dumps({"device": "gfx950", "picks": {"gemm3|9248|4096|1024|0|1": 99, "gemm|64|64|512|0|0": 15, "bogus|1|2": 1,
+                                                         "gemm3|x|1": 2}}))
+    ops._TILE.clear()
+    ops._FAMILY.clear()
+    ops._load_tile_cache()
+    assert ops._TILE.get(("gemm", 64, 64, 512, 0, 0)) == 15
+    assert ops._TILE.get(("gemm3", 9248, 4096, 1024, 0, 1)) != 99
+    assert not any(k[0] == "bogus" for k in ops._TILE)
