@@ -221,7 +221,7 @@ int sgic_l2norm_u8(const float *d_x, int ldx, int M, int D, float *d_unit, uint8
  *   under-filled launches), 5 = 64x128 (two workgroups per CU) workgroup tiles, 6 / 7 = 1 / 2 for the rows that
  *   fill whole rounds of the 256 CUs + 5 for the remaining rows (two launches), 8 / 9 = the same with 4 for the remaining rows,
  *   10 / 11 = 1 / 2 as a persistent launch (one resident workgroup per CU walks the tile list), 12 / 13 = 8 / 9 with the
- *   whole rounds walked persistently. */
+ *   whole rounds walked persistently, 14 / 15 = 256x128 tiles (plain / persistent). */
 int sgic_split3_f32(const float *d_x, int ld, int rows, int cols, int seg, int seg_stride, uint16_t *d_planes,
                     sgic_stream_t stream);
 int sgic_gemm_split3_f32(const float *d_A, int lda, int a_seg, int a_seg_stride, uint16_t *d_Aplanes,

@@ -478,7 +478,7 @@ extern "C" int sgic_split3_f32(const float *d_x, int ld, int rows, int cols, int
   return sgic::check_launch("split3_rows_kernel");
 }
 
-#define SGIC_SPLIT3_TILE_MODES 13
+#define SGIC_SPLIT3_TILE_MODES 15
 
 template <int WAVES_M, int WAVES_N, int BM, int BN, int NS, int KS = 1, bool PERSIST = false>
 static int s3_launch(const S3Args &g, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
@@ -509,6 +509,8 @@ static int s3_mode(const S3Args &g, int mode, hipStream_t st, hipEvent_t e0, hip
     case 4: return (g.K % 64 == 0 && g.conv_C % 64 == 0) ? s3_launch<2, 2, 1, 1, 3, 2>(g, st, e0, e1) : s3_launch<2, 2, 1, 1, 6>(g, st, e0, e1);
     case 10: return s3_launch<2, 4, 4, 4, 1, 1, true>(g, st, e0, e1);
     case 11: return s3_launch<2, 4, 4, 2, 1, 1, true>(g, st, e0, e1);
+    case 14: return s3_launch<4, 2, 4, 4, 1>(g, st, e0, e1);               // 256x128: the 128x256 tile's blocking for N = 128
+    case 15: return s3_launch<4, 2, 4, 4, 1, 1, true>(g, st, e0, e1);
     default: return s3_launch<2, 4, 2, 2, 1>(g, st, e0, e1);
   }
 }
@@ -525,7 +527,7 @@ static int s3_dispatch(const S3Args &g, const sgic_launch_opts *opts, hipStream_
   }
   const auto *evp = prof_next(opts);
   hipEvent_t e0 = evp ? evp->first : nullptr, e1 = evp ? evp->second : nullptr;
-  if ((mode >= 6 && mode <= 9) || mode >= 12) {
+  if ((mode >= 6 && mode <= 9) || mode == 12 || mode == 13) {
     // modes 6 / 7 = modes 1 / 2 for the rows that fill WHOLE rounds of the 256 CUs + the 64x128 two-per-CU tiles for the rest,
     // as two launches (the first ends on a full round, so nothing idles at the seam): a last round of big tiles that covers a
     // fraction of the chip costs a whole tile time, the small tiles finish it in about half.  One profiler record spans both.
@@ -560,7 +562,8 @@ static int s3_dispatch(const S3Args &g, const sgic_launch_opts *opts, hipStream_
 // workgroups per CU (finer rounds for grids that are not a multiple of the chip), 6 / 7 = 1 / 2 for the rows that fill whole rounds
 // of the chip + mode 5 for the remaining rows (two launches), 8 / 9 = the same with mode 4 for the remaining rows, 10 / 11 = 1 / 2
 // as a persistent launch (256 resident workgroups walk the tiles, the next tile's first loads fly during the epilogue), 12 / 13 =
-// 8 / 9 with the whole rounds walked persistently; bitwise identical results.
+// 8 / 9 with the whole rounds walked persistently, 14 / 15 = 256x128 tiles (plain / persistent: the 3x3 convolutions with 128
+// output channels); bitwise identical results.
 extern "C" int sgic_gemm_split3_f32(const float *d_A, int lda, int a_seg, int a_seg_stride, uint16_t *d_Aplanes,
                                     const uint16_t *d_Wplanes, const float *d_bias, const float *d_R, int ldr, float *d_C,
                                     int ldc, uint16_t *d_Cplanes, int M, int N, int K, int act, int c_seg, int c_seg_stride,
