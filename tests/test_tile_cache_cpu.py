@@ -91,3 +91,17 @@ def test_picks_of_another_build_are_dropped(ops, tmp_path):
     assert ops._TILE.get(("gemm", 64, 64, 512, 0, 0)) == 15
     assert ops._TILE.get(("gemm3", 9248, 4096, 1024, 0, 1)) != 99
     assert not any(k[0] == "bogus" for k in ops._TILE)
+
+
+def test_mode_ranges_agree_between_the_layers():
+    """the launch-mode ranges are written down in three places: the kernels' dispatchers (csrc), the tuner's mode lists (ops)
+    and the cache validator (ops._MAX_MODE): they must agree, or a tuned pick can be rejected by the C ABI"""
+    import re
+    import sgic_amd  # noqa
+    from sgic_amd import ops
+    csrc = os.path.join(os.path.dirname(os.path.abspath(ops.__file__)), "csrc")
+    split_max = int(re.search(r"#define SGIC_SPLIT3_TILE_MODES (\d+)", open(os.path.join(csrc, "gemm_split.hip")).read()).group(1))
+    f32_max = int(re.search(r"#define SGIC_TILE_MODES (\d+)", open(os.path.join(csrc, "gemm.hip")).read()).group(1))
+    assert max(ops.SPLIT3_MODES) == split_max == ops._MAX_MODE["gemm3"] == ops._MAX_MODE["conv3"]
+    assert max(ops.TUNE_MODES) == f32_max == ops._MAX_MODE["gemm"] == ops._MAX_MODE["conv3x3"]
+    assert max(ops.ATTN_MODES) == ops._MAX_MODE["attn"] == ops._MAX_MODE["attn3"] == 6
