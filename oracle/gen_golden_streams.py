@@ -11,6 +11,10 @@ Run:  make -C oracle && python oracle/gen_golden_streams.py      -> tests/golden
       python oracle/gen_golden_streams.py --large                -> tests/golden/streams_large.npz: two 256x256 images through
       the PRODUCTION architecture (TiTok ViT-L, 24 layers, 768-wide detail branch) of the real reference, with z and h
       kept as well, so the large model is pinned against the reference itself and not only against oracle/torch_ref.py
+      python oracle/gen_golden_streams.py --sigma                -> tests/golden/streams_small_sigma.npz: the reference's sigma
+      (scales_w_k, compression_model.py:317-353, as fp32 bit patterns) at every coded position of the same 33 images and
+      nothing else; with it tests/test_gpu_streams.py attributes every index flip to its cause (same sigma, different index =
+      the index arithmetic, entropy_models.py:355-362; different sigma = the arithmetic upstream).  Does not rewrite the main file.
 """
 import os
 import sys
@@ -35,6 +39,8 @@ from entropy.compression_model import get_padding_size  # noqa: E402  (reference
 from models.codec_sq_fixbpp import Hybrid_Codec  # noqa: E402  (reference code)
 
 BIG = "--large" in sys.argv
+SIGMA = "--sigma" in sys.argv and not BIG
+sig_out = {}
 cfg = LARGE if BIG else SMALL
 torch.manual_seed(0)
 torch.set_num_threads(8)
@@ -67,6 +73,10 @@ for name, H, Wd, seed in cases:
                                     y_spatial_prior_reduction=bn.y_spatial_prior_reduction)
     sym = torch.stack([t.clamp(-30000, 30000).to(torch.int16)[0] for t in r[0:4]])
     idx = torch.stack([bn.gaussian_encoder.build_indexes(s, bn.force_zero_thres).to(torch.int16)[0] for s in r[4:8]])
+    if SIGMA:
+        sig_out[f"{name}.sigma"] = torch.stack([t[0] for t in r[4:8]]).numpy().astype(np.float32)
+        print(f"{name}: sigma {sig_out[f'{name}.sigma'].shape}", flush=True)
+        continue
     stream = bn.compress(h, 0)                                                         # the reference's own coder (oracle/_ref)
     y_hat_dec = None
     # the reference's decoder on its own stream: y_hat before the synthesis transform
@@ -86,6 +96,11 @@ for name, H, Wd, seed in cases:
         out[f"{name}.z"], out[f"{name}.h"], out[f"{name}.y"] = z.numpy(), h.numpy(), y.numpy()
     print(f"{name}: {H}x{Wd} -> {tuple(x.shape[2:])} tiles {stack} stream {len(stream)} B coded {int((idx >= 0).sum())}/{idx.numel()} "
           f"|sym|max {int(sym.abs().max())}", flush=True)
+if SIGMA:
+    dst = os.path.join(ROOT, "tests", "golden", "streams_small_sigma.npz")
+    np.savez_compressed(dst, **sig_out)
+    print("wrote", dst, os.path.getsize(dst), "bytes")
+    sys.exit(0)
 dst = os.path.join(ROOT, "tests", "golden", "streams_large.npz" if BIG else "streams_small.npz")
 np.savez_compressed(dst, **out)
 print("wrote", dst, os.path.getsize(dst), "bytes")

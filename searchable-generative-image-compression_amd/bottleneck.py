@@ -141,9 +141,10 @@ class BottleneckHIP:
         y = ops.colop(y, self.enc_q, 0)
         return dcb4_forward(dcb4_forward(y, self.enc1[0], B, H, W), self.enc1[1], B, H, W)
 
-    def quantise(self, y, B, H, W):
+    def quantise(self, y, B, H, W, sigma_taps=None):
         """forward_four_part_prior(write=True) + build_indexes (compression_model.py:303-366,
-        entropy_models.py:355-362): -> sym, idx (B, 4, Q/4, H, W) int16 on device, ctx buffer"""
+        entropy_models.py:355-362): -> sym, idx (B, 4, Q/4, H, W) int16 on device, ctx buffer.
+        sigma_taps: a list that receives the four steps' sigma maps [(B H W), Q] (tests: attribution of index flips)"""
         Q, hw = self.Q, H * W
         paramsB, commonB = self._prior(B, H, W)
         yq = ops.colop(y, paramsB[:, 0:Q], 1)                       # y / clamp_min(q_step, 0.5)
@@ -153,11 +154,15 @@ class BottleneckHIP:
         idx = torch.empty_like(sym)
         thr = self.force_zero_thres
         ops.quant_step(yq, paramsB[:, Q:2 * Q], paramsB[:, 2 * Q:], 3 * Q, ctx, 2 * Q, B, H, W, Q, 0, thr, sym, idx)
+        if sigma_taps is not None:
+            sigma_taps.append(paramsB[:, Q:2 * Q].clone())
         for k in (1, 2, 3):
             t = dcb4_forward(ctx, self.adaptor[k], B, H, W)
             for w in self.prior:
                 t = dcb4_forward(t, w, B, H, W)
             ops.quant_step(yq, t[:, 0:Q], t[:, Q:], 2 * Q, ctx, 2 * Q, B, H, W, Q, k, thr, sym, idx)
+            if sigma_taps is not None:
+                sigma_taps.append(t[:, 0:Q].clone())
         return sym, idx, ctx, paramsB
 
     def compress(self, h, B, H, W):

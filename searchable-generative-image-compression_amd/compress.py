@@ -58,6 +58,17 @@ def stem_of(path):
     return os.path.splitext(os.path.basename(path))[0]
 
 
+def unique_stems(files):
+    """Inputs that share a stem (a.jpg, a.png) write the SAME <stem>.c2df / <stem>.npy.  The reference's sequential loop leaves the
+    later file's outputs on disk for both (compress.py:248-291); a batched, multi-threaded, sharded driver must not leave that to
+    the order batches or writer threads happen to finish in, so only the sorted-LAST file of a stem is encoded at all: the same
+    final files and index entry, decided up front.  -> the sorted list without the shadowed files."""
+    last = {}
+    for i, p in enumerate(files):
+        last[stem_of(p)] = i
+    return [p for i, p in enumerate(files) if last[stem_of(p)] == i]
+
+
 def assemble_index(files, vecs, bit_dir, index_dir, dim):
     """Rank-0 index assembly (compress.py:295-306).  The reference walks `sorted(glob(clip_dir/*.npy))` -- i.e. the
     UNIQUE stems ordered by the string "<stem>.npy" -- and adds a vector for every stem whose .c2df exists, with the
@@ -105,12 +116,16 @@ def main(argv=None):
     from .ingest import DeviceIngest, ShardLoader
     from .pipeline import CompressPipeline
 
+    # launched by torchrun / bench.py-style launchers (WORLD_SIZE set, even to 1): one rank per GPU over RCCL, and every
+    # collective below runs -- a 1-rank job takes the code path of an 8-rank job.  Plain `python compress.py`: no process group.
+    distributed = "WORLD_SIZE" in os.environ
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world > 1:
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method="env://")
-        local = int(os.environ.get("LOCAL_RANK", "0"))
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=os.environ.get("SGIC_DIST_BACKEND", "nccl"), init_method="env://", rank=rank, world_size=world)
+        local = int(os.environ.get("LOCAL_RANK", str(args.gpu_idx)))
     else:
         local = args.gpu_idx
     torch.cuda.set_device(local)
@@ -130,10 +145,10 @@ def main(argv=None):
     if rank == 0:
         for d in (args.save_dir, bit_dir, index_dir, clip_dir):
             os.makedirs(d, exist_ok=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
 
-    files = sorted(glob(os.path.join(args.dataset_dir, "*.*")))
+    files = unique_stems(sorted(glob(os.path.join(args.dataset_dir, "*.*"))))
     lo, hi = shard_range(len(files), rank, world)
     mine = files[lo:hi]
     vecs = np.zeros((len(mine), ccfg.embed_dim), dtype=np.float32)
@@ -193,7 +208,7 @@ def main(argv=None):
     dt = time.perf_counter() - t_start
 
     # every rank reaches this point, failed or not: the error flag travels first so that nobody blocks in the gather
-    if world > 1:
+    if distributed:
         flag = torch.tensor([1.0 if failed is not None else 0.0], device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if float(flag.item()) > 0:
@@ -206,16 +221,17 @@ def main(argv=None):
         raise failed
     allv = gather_vectors(torch.from_numpy(vecs).to(dev), len(files), rank, world).cpu().numpy()
     rate = torch.tensor([len(mine) / dt if dt > 0 else 0.0], device=dev, dtype=torch.float64)
-    if world > 1:
+    if distributed:
         dist.all_reduce(rate, op=dist.ReduceOp.SUM)
     if rank == 0:
         assemble_index(files, allv, bit_dir, index_dir, ccfg.embed_dim)
         print(json.dumps({"cli_images_per_s": round(float(rate.item()), 2), "images": len(files), "n_gpus": world,
+                          "collectives": (dist.get_backend() if distributed else None),
                           "seconds_rank0": round(dt, 3), "batch_size": args.batch_size,
                           "note": "files -> .c2df: header pass, JPEG/PNG decode, H2D, encoder+entropy+CLIP, container + .npy writes"}),
               flush=True)
     ops.save_tile_cache()
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
     return 0
 

@@ -101,9 +101,19 @@ struct S3Args {
 // exposed LDS latency per 64 k instead of per 32 k, which is what bounds a launch of one wave per SIMD.
 // PERSIST: gridDim.x resident workgroups (one per CU) walk the tile list; the next tile's first K stage is requested BEFORE the
 // current tile's epilogue, so the first-load latency of a tile hides behind the previous tile's stores.
+// Diagnostic build only (tools/micro/launch_latency.hip defines S3_STAMPS): s_memrealtime (100 MHz) of the first workgroup's
+// start and the last workgroup's end, and s_memtime (shader clock) over the same span of workgroup 0 -- what a launch takes
+// on the shader array itself, beside its dispatch timestamps.  No stamp executes in the product build.
+#ifdef S3_STAMPS
+__device__ unsigned long long s3_stamps[4] = {~0ull, 0ull, 0ull, 0ull};   // min start, max end (realtime); wg 0: start, end (s_memtime)
+#endif
+
 template <int WAVES_M, int WAVES_N, int BM, int BN, int NS, int KS, bool PERSIST>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (2 * 3 * 16 * (BM * WAVES_M + BN * WAVES_N) * 64 * KS <= 80 * 1024 && WAVES_M * WAVES_N == 8) ? 2 : 1)
 void gemm_split3_kernel(S3Args g) {
+#ifdef S3_STAMPS
+  const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime(), st_c0 = __builtin_amdgcn_s_memtime();
+#endif
   static_assert(KS == 1 || KS == 2, "32-k slices per stage");
   static_assert(!PERSIST || NS == 1, "the persistent walk is built on the one-register-set pipeline");
   constexpr int NT = 64 * WAVES_M * WAVES_N, TM = 16 * BM * WAVES_M, TN = 16 * BN * WAVES_N;
@@ -459,6 +469,19 @@ void gemm_split3_kernel(S3Args g) {
       }
     }
     tile_epilogue(em0, en0);
+#ifdef S3_STAMPS
+    if (!more_tiles) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left the wave
+      if (threadIdx.x == 0) {
+        atomicMin(&s3_stamps[0], st_rt0);
+        atomicMax(&s3_stamps[1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+        if (blockIdx.x == 0) {
+          s3_stamps[2] = st_c0;
+          s3_stamps[3] = __builtin_amdgcn_s_memtime();
+        }
+      }
+    }
+#endif
     if (!more_tiles) break;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // every wave is done with its epilogue slice before the staging buffers are refilled
@@ -484,11 +507,15 @@ template <int WAVES_M, int WAVES_N, int BM, int BN, int NS, int KS = 1, bool PER
 static int s3_launch(const S3Args &g, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
   constexpr int NT = 64 * WAVES_M * WAVES_N, TM = 16 * BM * WAVES_M, TN = 16 * BN * WAVES_N;
   constexpr int LDS = 2 * 3 * (TM + TN) * 64 * KS;
-  static bool attr_set = false;   // idempotent: a race sets the same value twice
+  // the dynamic-LDS limit is a per-DEVICE attribute of the function: remembered per device (a process that launches on a
+  // second GPU raises it there too); idempotent, so a race only sets the same value twice
+  static bool attr_set[64] = {};
   auto kernel = gemm_split3_kernel<WAVES_M, WAVES_N, BM, BN, NS, KS, PERSIST>;
-  if (!attr_set) {
+  int dev = 0;
+  SGIC_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
     SGIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   unsigned ntiles = (unsigned)(((g.M + TM - 1) / TM) * ((g.N + TN - 1) / TN));
   const dim3 grid(PERSIST ? (ntiles < 256u ? ntiles : 256u) : ntiles);   // persistent: one resident workgroup per CU

@@ -15,8 +15,13 @@ def shard_range(n, rank, world):
 
 def gather_vectors(local, n_total, rank, world):
     """local: (n_local, D) fp32 rows of this rank's contiguous shard -> (n_total, D) on every rank.
-    Shards differ by at most one row, so each rank pads to ceil(n/world) rows and the pad is dropped."""
-    if world == 1:
+    Shards differ by at most one row, so each rank pads to ceil(n/world) rows and the pad is dropped.
+    Without a process group (plain single-process run) the shard is the whole; WITH one the collective runs even at
+    world 1 -- a `torchrun --nproc-per-node 1` job takes exactly the code path of an 8-rank job."""
+    if not (dist.is_available() and dist.is_initialized()):
+        assert world == 1, "world > 1 needs an initialised process group"
+        return local
+    if n_total == 0:
         return local
     D = local.shape[1]
     per = (n_total + world - 1) // world

@@ -2,11 +2,7 @@
 
 
 def get_padding_size(height, width, p=64):
-    """entropy/compression_model.py:13-22 -- right/bottom padding to a multiple of p"""
-    new_h = (height + p - 1) // p * p
-    new_w = (width + p - 1) // p * p
-    padding_left = 0
-    padding_right = new_w - width - padding_left
-    padding_top = 0
-    padding_bottom = new_h - height - padding_top
-    return padding_left, padding_right, padding_top, padding_bottom
+    """(left, right, top, bottom) padding that brings (height, width) up to multiples of p -- all of it on the right /
+    bottom edge, as the reference pads (entropy/compression_model.py:13-22; consumed by F.pad(..., mode="replicate"),
+    compress.py:258-261)"""
+    return 0, -width % p, 0, -height % p

@@ -27,9 +27,11 @@ def unit_rows(x, floor=1e-9):
 
 
 def codes_to_unit(codes_u8):
-    """inverse of the compress side's u8 quantiser (compress.py:77, `round((z*0.5+0.5)*255)`): code c -> c/255*2-1,
-    then back onto the unit sphere (the quantiser moved the vector off it by up to half a step per coordinate)"""
-    return unit_rows(np.asarray(codes_u8, dtype=np.float32) * np.float32(2.0 / 255.0) - np.float32(1.0))
+    """inverse of the compress side's u8 quantiser (compress.py:77, `round((z*0.5+0.5)*255)`): code c -> c/255*2-1 in the
+    reference's operation order (search.py:21: divide, then scale, then shift -- `c * (2/255) - 1` differs by one fp32 ulp for 111
+    of the 256 codes, enough to reorder near-ties), then back onto the unit sphere (the quantiser moved the vector off it by up
+    to half a step per coordinate)"""
+    return unit_rows((np.asarray(codes_u8).astype(np.float32) / np.float32(255.0)) * np.float32(2.0) - np.float32(1.0))
 
 
 def embedded_clip_vector(path):

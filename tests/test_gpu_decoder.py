@@ -1,6 +1,6 @@
 """GPU parity of the decode path (D1-D5) against golden outputs of the REAL reference modules
 (tests/golden/dec_small_*.npz, oracle/gen_golden_dec.py) and round-trip properties.
-Tolerance 5e-4 * max|ref| for float tensors (the VQGAN stack amplifies fp32 ordering noise a little more than
+Tolerance 2e-5 * max|ref| (measured 1e-6 ... 2.5e-6) for float tensors (the VQGAN stack amplifies fp32 ordering noise a little more than
 the encoder: 30+ GroupNorm/conv layers), pixels additionally as PSNR vs the reference reconstruction."""
 import os
 
@@ -9,7 +9,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-TOL = 5e-4
+TOL = 2e-5
 
 
 @pytest.fixture(scope="module")
@@ -79,7 +79,7 @@ def test_decode_vs_reference_golden(case, codec, golden_dir):
     psnr = 10 * np.log10(4.0 / max(mse, 1e-20))
     print(f"case {case}: rel err {{{', '.join(f'{k} {v:.1e}' for k, v in e.items())}}}  PSNR vs reference recon {psnr:.1f} dB")
     assert all(v < TOL for k, v in e.items() if k != "x_hat"), e
-    assert e["x_hat"] < 2e-3 and psnr > 80.0
+    assert e["x_hat"] < 2e-4 and psnr > 100.0        # measured: max |dx| 4e-5, PSNR 110-112 dB vs the reference's reconstruction
     assert x_hat.shape == (B, 3, H, W) and float(x_hat.abs().max()) <= 1.0
 
 

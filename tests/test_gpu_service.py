@@ -125,6 +125,7 @@ def test_file_endpoint_status_codes(svc):
     assert s.preview_url_for_path("im1.png").endswith("im1.png")          # found by name under the media roots
 
 
+@pytest.mark.perf
 def test_model_is_built_once_and_requests_are_fast(svc):
     """the point of the resident object: after the one-off build, a request is milliseconds, not a model build"""
     import time

@@ -52,19 +52,57 @@ def _groups(g):
     return by
 
 
-def test_encode_side_streams_vs_reference(setup):
+def _coded_sigma(taps, B, hh, ww, Q):
+    """our sigma at the coded positions, arranged like the reference's scales_w_k (B, 4, Q/4, h, w): at step k and position
+    (i, j) the active quarter is p ^ {0,3,2,1}[k], p = 2 (i & 1) + (j & 1) (compression_model.py:277-280)"""
+    q4 = Q // 4
+    out = np.zeros((B, 4, q4, hh, ww), dtype=np.float32)
+    ii, jj = np.meshgrid(np.arange(hh), np.arange(ww), indexing="ij")
+    p = 2 * (ii & 1) + (jj & 1)
+    for k, t in enumerate(taps):
+        s = t.cpu().numpy().reshape(B, hh, ww, Q)
+        quarter = p ^ [0, 3, 2, 1][k]
+        for c in range(q4):
+            out[:, k, c] = np.take_along_axis(s, (quarter * q4 + c)[None, :, :, None], axis=3)[..., 0]
+    return out
+
+
+def test_encode_side_streams_vs_reference(setup, golden_dir):
     g, codec, cfg = setup
+    sig_path = os.path.join(golden_dir, "streams_small_sigma.npz")
+    gsig = np.load(sig_path) if os.path.exists(sig_path) else None
     total = ident = sym_flips = idx_flips = n_sym = 0
     vq_mismatch = 0
     per_image = {}
+    causes = {"same_sigma_different_index": 0, "sigma_differs": 0, "details": []}
+    sig_stats = {"positions": 0, "bitwise_equal": 0, "max_ulps": 0}
     for (Hp, Wp), cases in _groups(g).items():
         x = torch.cat([_input(H, W, seed) for _, H, W, seed in cases])
         encs = codec.encode_batch(x)
         r = codec.encode_device(x)
         sym, idx, vq = r["sym"].cpu().numpy(), r["idx"].cpu().numpy(), r["vq"].cpu().numpy().reshape(len(cases), -1)
+        taps = []
+        bn = codec.bottleneck
+        hh, ww = r["feat_hw"]
+        bn.quantise(bn.analysis(r["h"], len(cases), hh, ww), len(cases), hh, ww, sigma_taps=taps)
+        ours = _coded_sigma(taps, len(cases), hh, ww, bn.Q)
         for b, (name, H, W, seed) in enumerate(cases):
             gs, gi = g[f"{name}.sym"], g[f"{name}.idx"]
             sf, jf = int((sym[b] != gs).sum()), int((idx[b] != gi).sum())
+            if gsig is not None:
+                # attribution of every index flip (VERDICT r2 item 9): the reference's sigma at the same position, as bits
+                ref_sig = gsig[f"{name}.sigma"]
+                coded = gi >= 0
+                a, bb = ours[b][coded].view(np.int32).astype(np.int64), ref_sig[coded].view(np.int32).astype(np.int64)
+                sig_stats["positions"] += int(coded.sum())
+                sig_stats["bitwise_equal"] += int((a == bb).sum())
+                sig_stats["max_ulps"] = max(sig_stats["max_ulps"], int(np.abs(a - bb).max()) if a.size else 0)
+                for pos in zip(*np.nonzero(idx[b] != gi)):
+                    so, sr = float(ours[b][pos]), float(ref_sig[pos])
+                    same = np.float32(so).view(np.int32) == np.float32(sr).view(np.int32)
+                    causes["same_sigma_different_index" if same else "sigma_differs"] += 1
+                    causes["details"].append({"image": name, "pos": [int(v) for v in pos], "sigma_ours": so.hex(), "sigma_ref": sr.hex(),
+                                              "idx_ours": int(idx[b][pos]), "idx_ref": int(gi[pos])})
             same = encs[b]["h_bit_stream"] == g[f"{name}.stream"].tobytes()
             # identical symbols + indexes must give the reference's bytes; the converse does not hold (an index flip between
             # two table rows whose cdf entry for that symbol coincides leaves the stream unchanged)
@@ -72,16 +110,18 @@ def test_encode_side_streams_vs_reference(setup):
             vq_mismatch += int((vq[b] != g[f"{name}.vq"].astype(np.int64)).sum())
             total, ident, sym_flips, idx_flips, n_sym = total + 1, ident + int(same), sym_flips + sf, idx_flips + jf, n_sym + gs.size
             per_image[name] = {"sym_flips": sf, "idx_flips": jf, "stream_identical": bool(same)}
-            assert (sf + jf) / gs.size <= 0.005, f"{name}: {sf} symbol / {jf} index flips of {gs.size}"
+            assert sf == 0 and jf <= 2, f"{name}: {sf} symbol / {jf} index flips of {gs.size}"
     report = {"streams_identical": ident, "total": total, "symbol_flips": sym_flips, "index_flips": idx_flips, "symbols": n_sym,
-              "vq_index_mismatches": vq_mismatch, "per_image": per_image}
+              "vq_index_mismatches": vq_mismatch, "index_flip_causes": causes, "sigma_vs_reference": sig_stats, "per_image": per_image}
     print("\n[stream parity, encode side] " + json.dumps({k: v for k, v in report.items() if k != "per_image"}))
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out):
         json.dump(report, open(os.path.join(out, "stream_parity_encode.json"), "w"), indent=1)
-    assert vq_mismatch <= total * 32 * 0.01          # TiTok token flips: <= 1 % (nearest-code ties at fp32 noise level)
-    assert (sym_flips + idx_flips) / n_sym <= 0.001  # overall flip rate over the whole fixture: <= 0.1 %
-    assert ident >= total // 2                       # most streams are byte-identical end to end
+    # The bar is the claimed level with one chance event of headroom (round 2 measured 32 / 33 identical, 0 symbol flips, 2 index
+    # flips in 196 608, 0 VQ mismatches; the kernels are bitwise independent of tile choice and batch, so a box does not change it):
+    assert total == 33 and vq_mismatch == 0          # every TiTok token equals the reference's
+    assert sym_flips == 0 and idx_flips <= 6         # <= 3e-5 of the coded positions (a sigma within fp32 noise of a bin edge)
+    assert ident >= 31                               # streams byte-identical to the reference's, end to end
 
 
 def test_every_reference_stream_decodes(setup):
@@ -144,7 +184,7 @@ def test_every_reference_stream_decodes(setup):
     # a flip is a chance event (a sigma within ~1e-7 relative of a bin edge, where two fp32 implementations disagree): about 2 are
     # expected over the 196 608 coded positions of this fixture (observed: 1 with SGIC_GEMM=f32, 4 with the default split GEMM, at
     # identical error levels against the reference's activations; DESIGN section 4 on why the rates differ); every one must be REPAIRED
-    assert repaired <= 6 and idx_flips <= 8
+    assert decoded == 33 and repaired <= 3 and idx_flips <= 6
 
 
 def test_decompress_repairs_and_rejects(setup):

@@ -101,3 +101,29 @@ def test_get_padding_size_is_the_one_mirror():
     assert compress.get_padding_size is get_padding_size
     assert get_padding_size(859, 1000, p=256) == (0, 24, 0, 165)        # the reference's apple.jpg geometry -> 1024 x 1024
     assert "def get_padding_size" not in inspect.getsource(compress)
+
+
+def test_duplicate_stems_keep_only_the_sorted_last_file():
+    """a.jpg and a.png of different geometry must not race for a.c2df / a.npy -- the earlier one is never encoded"""
+    from sgic_amd.compress import unique_stems
+    files = sorted(["d/a.jpg", "d/a.png", "d/b.png", "d/c.jpeg", "d/c.jpg", "d/c.png", "d/z.bmp"])
+    assert unique_stems(files) == ["d/a.png", "d/b.png", "d/c.png", "d/z.bmp"]
+    assert unique_stems([]) == [] and unique_stems(["x/only.png"]) == ["x/only.png"]
+
+
+def test_codes_to_unit_is_the_reference_expression_for_all_256_codes():
+    """search.py:21 of the reference computes (q / 255.0) * 2.0 - 1.0 in fp32; c * (2/255) - 1 is one ulp off for 111 codes"""
+    import numpy as np
+    from sgic_amd.search import codes_to_unit, unit_rows
+    c = np.arange(256, dtype=np.uint8)
+    ref = (c.astype(np.float32) / 255.0) * 2.0 - 1.0
+    assert ref.dtype == np.float32 and np.array_equal(codes_to_unit(c), unit_rows(ref))
+    assert int((ref != c.astype(np.float32) * np.float32(2.0 / 255.0) - np.float32(1.0)).sum()) == 111
+
+
+def test_get_padding_size_pads_right_and_bottom_to_the_multiple():
+    from sgic_amd.entropy.compression_model import get_padding_size
+    for h, w, p in [(859, 1000, 256), (256, 256, 256), (1, 1, 64), (257, 512, 256), (64, 65, 64), (1024, 1, 256)]:
+        nh, nw = (h + p - 1) // p * p, (w + p - 1) // p * p
+        assert get_padding_size(h, w, p) == (0, nw - w, 0, nh - h)
+    assert get_padding_size(100, 100) == (0, 28, 0, 28)          # default p = 64 as the reference
