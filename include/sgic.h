@@ -221,7 +221,9 @@ int sgic_l2norm_u8(const float *d_x, int ldx, int M, int D, float *d_unit, uint8
  *   under-filled launches), 5 = 64x128 (two workgroups per CU) workgroup tiles, 6 / 7 = 1 / 2 for the rows that
  *   fill whole rounds of the 256 CUs + 5 for the remaining rows (two launches), 8 / 9 = the same with 4 for the remaining rows,
  *   10 / 11 = 1 / 2 as a persistent launch (one resident workgroup per CU walks the tile list), 12 / 13 = 8 / 9 with the
- *   whole rounds walked persistently, 14 / 15 = 256x128 tiles (plain / persistent). */
+ *   whole rounds walked persistently, 14 / 15 = 256x128 tiles (plain / persistent), 16 / 17 = 2 / 11 with LDS-DMA staging.
+ *   The 128x256 and 256x128 tiles (1, 10, 14, 15 and the whole-round part of 6, 8, 12) stage their operands by LDS-DMA
+ *   (global_load_lds: no register pass, no ds_write), the other tiles through registers; all modes are bitwise identical. */
 int sgic_split3_f32(const float *d_x, int ld, int rows, int cols, int seg, int seg_stride, uint16_t *d_planes,
                     sgic_stream_t stream);
 int sgic_gemm_split3_f32(const float *d_A, int lda, int a_seg, int a_seg_stride, uint16_t *d_Aplanes,
@@ -299,6 +301,17 @@ int sgic_pad_replicate(const float *d_in, float *d_out, int BC, int H, int W, in
  * Bit-identical to the torch ops (one IEEE division, multiply, subtract per sample). */
 int sgic_u8hwc_to_f32chw_pad(const uint8_t *d_in, float *d_out, int B, int H, int W, int pl, int pr, int pt, int pb,
                              sgic_stream_t stream);
+
+/* Baseline JPEG decode of a batch of B equal-geometry files to RGB u8 HWC (B, H, W, 3) on the device -- the pixel decode inside
+ * the reference's Test_Dataset (`Image.open(path).convert("RGB")`, compress.py:151-168), bit-exact with Pillow / libjpeg-turbo's
+ * default decoder (islow IDCT, fancy chroma upsampling, jdcolor tables).  The host parses markers and strips byte stuffing
+ * (sgic_amd/jpeg.py); Huffman decoding, IDCT, upsampling and colour conversion run here.  d_params: B x 64 int32 descriptors,
+ * d_scan: cleaned entropy-coded segments (each padded to a multiple of 2048 B), d_tabs: B x 4 lookup tables of 1424 B,
+ * d_segs: restart-interval byte offsets, d_quant: u16 tables in natural order, d_coef / d_planes: workspaces,
+ * d_err[b]: 0 ok / 1 invalid code / 2 missing restart segment. */
+int sgic_jpeg_decode_batch(const int32_t *d_params, const uint8_t *d_scan, const uint8_t *d_tabs, const int32_t *d_segs,
+                           const uint16_t *d_quant, int16_t *d_coef, uint8_t *d_planes, uint8_t *d_out, int32_t *d_err, int B, int H,
+                           int W, int max_blocks, sgic_stream_t stream);
 
 /* CLIP text tower front end: out[b*L+l,:] = table[ids[b,l],:] + pos[l,:] (open_clip CLIP.encode_text, reached from
  * search.py:93-97; ids outside [0,vocab) are clamped).  D multiple of 4. */

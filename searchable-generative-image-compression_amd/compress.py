@@ -162,6 +162,10 @@ def main(argv=None):
         """host side of one batch: .c2df container + clip vector per image (compress.py:268-291)"""
         h, batch, pad, copied = job
         copied.synchronize()
+        if batch.jpeg is not None:            # decoded on the GPU: a corrupt entropy-coded segment shows up as an error code
+            codes = batch.jpeg.last_err.cpu().numpy()
+            if codes.any():
+                raise RuntimeError(f"corrupt JPEG data in {[p for p, c in zip(batch.paths, codes) if c]} (codes {codes[codes != 0].tolist()})")
         batch.release()                       # the pinned u8 buffer goes back to the decode threads
         pl, pr, pt, pb = pad
         for j, (i, streams) in enumerate(zip(batch.indices, pipe.finish(h))):

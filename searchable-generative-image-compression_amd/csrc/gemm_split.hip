@@ -80,6 +80,120 @@ struct S3Args {
   int m_base;                    // logical row of this launch's row 0 (second launch of the split modes 6 / 7): enters the C row map
 };
 
+// ---- epilogue of one tile, shared by the register-staged and the LDS-DMA kernel: the accumulators hold
+// C[m = block row base + l16][n = block column base + 4 lq .. + 3].  bias -> activation -> residual, as gemm.hip.  Wide path: the wave
+// re-distributes its tile through its own LDS slice `ep` (row stride + 4 floats: conflict-free ds_write_b128) so that a store
+// instruction writes whole row segments (16 BN floats per row), as float4 or -- when the consumer is the next GEMM -- directly as
+// bf16x3 planes.  PASSES: the tile goes through the slice in that many groups of block rows (1: the slice holds the wave's whole
+// tile, 16 BM rows; 2: half of it at a time -- the LDS-DMA kernel, whose other staging buffer is being filled meanwhile).
+template <int BM, int BN, int PASSES>
+__device__ __forceinline__ void s3_tile_epilogue(const S3Args &g, f32x4 (&acc)[BM][BN], float *ep, int em0, int en0, int wm, int wn, int lane) {
+  const int l16 = lane & 15, lq = lane >> 4;
+  if (g.vec_epilogue) {
+    constexpr int BMP = BM / PASSES, RM = 16 * BMP, CN = 16 * BN, LDW = CN + 4, LPR = CN / 4, RPI = 64 / LPR, NIT = RM / RPI;
+    static_assert(BM % PASSES == 0 && RM % RPI == 0, "epilogue passes");
+    const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
+    const int n = en0 + wn + c4;
+    const bool colok = n < g.N;
+    const int nc = colok ? n : 0;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias && colok) bv = *reinterpret_cast<const f32x4 *>(g.bias + n);
+    s3_for<PASSES>([&](auto pass_c) __attribute__((always_inline)) {   // compile-time pass index: acc[][] stays in registers
+      constexpr int pass = decltype(pass_c)::value;
+#pragma unroll
+      for (int i = 0; i < BMP; i++)
+#pragma unroll
+        for (int j = 0; j < BN; j++) *reinterpret_cast<f32x4 *>(ep + (i * 16 + l16) * LDW + j * 16 + 4 * lq) = acc[pass * BMP + i][j];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int wmp = wm + pass * RM;
+      auto run = [&](auto act_c, auto res_c, auto pl_c) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(act_c)::value;
+        constexpr bool HASR = decltype(res_c)::value != 0, PLANES = decltype(pl_c)::value != 0;
+        constexpr int EB = NIT < 8 ? NIT : 8;    // rows in flight between the LDS read / residual load and the store
+#pragma unroll
+        for (int b = 0; b < NIT; b += EB) {
+          f32x4 cv[EB], rv[EB];
+#pragma unroll
+          for (int q = 0; q < EB; ++q) {
+            const int rr = (b + q) * RPI + r0;
+            cv[q] = *reinterpret_cast<const f32x4 *>(ep + rr * LDW + c4);
+            if constexpr (HASR) rv[q] = *reinterpret_cast<const f32x4 *>(g.R + (size_t)(min(em0 + wmp + rr, g.M - 1) + g.m_base) * g.ldr + nc);
+          }
+#pragma unroll
+          for (int q = 0; q < EB; ++q) {
+            const int m = em0 + wmp + (b + q) * RPI + r0;
+            f32x4 v = cv[q];
+#pragma unroll
+            for (int t = 0; t < 4; t++) v[t] = apply_act_c<ACT>(v[t] + bv[t]);
+            if constexpr (HASR) v += rv[q];
+            if (colok && m < g.M) {
+              if constexpr (PLANES) {
+                s3_store4(g.Cp, g.c_plane, (size_t)(m + g.m_base) * g.N + n, v);
+              } else {
+                const int mm = m + g.m_base;
+                const size_t crow = g.c_seg ? (size_t)(mm / g.c_seg) * g.c_seg_stride + (mm % g.c_seg) : (size_t)mm;
+                *reinterpret_cast<f32x4 *>(g.C + crow * g.ldc + n) = v;
+              }
+            }
+          }
+        }
+      };
+      auto run_act = [&](auto act_c) __attribute__((always_inline)) {
+        if (g.Cp) {
+          if (g.R) run(act_c, IntC<1>{}, IntC<1>{});
+          else run(act_c, IntC<0>{}, IntC<1>{});
+        } else {
+          if (g.R) run(act_c, IntC<1>{}, IntC<0>{});
+          else run(act_c, IntC<0>{}, IntC<0>{});
+        }
+      };
+      switch (g.act) {
+        case ACT_GELU: run_act(IntC<ACT_GELU>{}); break;
+        case ACT_SILU: run_act(IntC<ACT_SILU>{}); break;
+        case ACT_TANH: run_act(IntC<ACT_TANH>{}); break;
+        case ACT_LRELU: run_act(IntC<ACT_LRELU>{}); break;
+        default: run_act(IntC<ACT_NONE>{}); break;
+      }
+    });
+    return;
+  }
+  // narrow path (N or the leading dimensions not float4-addressable): one dword at a time from the accumulators
+  auto run = [&](auto act_c, auto res_c) __attribute__((always_inline)) {
+    constexpr int ACT = decltype(act_c)::value;
+    constexpr bool HASR = decltype(res_c)::value != 0;
+#pragma unroll
+    for (int j = 0; j < BN; j++) {
+      const int n = en0 + wn + j * 16 + 4 * lq;
+#pragma unroll
+      for (int i = 0; i < BM; i++) {
+        const int m = em0 + wm + i * 16 + l16;
+        if (m >= g.M) continue;
+        const int mm = m + g.m_base;
+        const size_t crow = g.c_seg ? (size_t)(mm / g.c_seg) * g.c_seg_stride + (mm % g.c_seg) : (size_t)mm;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          if (n + t < g.N) {
+            float o = apply_act_c<ACT>(acc[i][j][t] + (g.bias ? g.bias[n + t] : 0.f));
+            if constexpr (HASR) o += g.R[(size_t)mm * g.ldr + n + t];
+            g.C[crow * g.ldc + n + t] = o;
+          }
+        }
+      }
+    }
+  };
+  auto run_act = [&](auto act_c) __attribute__((always_inline)) {
+    if (g.R) run(act_c, IntC<1>{});
+    else run(act_c, IntC<0>{});
+  };
+  switch (g.act) {
+    case ACT_GELU: run_act(IntC<ACT_GELU>{}); break;
+    case ACT_SILU: run_act(IntC<ACT_SILU>{}); break;
+    case ACT_TANH: run_act(IntC<ACT_TANH>{}); break;
+    case ACT_LRELU: run_act(IntC<ACT_LRELU>{}); break;
+    default: run_act(IntC<ACT_NONE>{}); break;
+  }
+}
+
 // Tile = (16 BM WAVES_M) x (16 BN WAVES_N); every wave owns BM x BN blocks of 16 x 16 on v_mfma_f32_16x16x32_bf16 (one MFMA =
 // one plane pair over a whole 32-k slice).  The W fragment is passed as the MFMA's first operand, so a lane ends up with 4
 // CONSECUTIVE columns of one C row (row = lane & 15, columns 4 (lane >> 4) ..): the epilogue stores float4 / 8-byte plane
@@ -104,8 +218,18 @@ struct S3Args {
 // Diagnostic build only (tools/micro/launch_latency.hip defines S3_STAMPS): s_memrealtime (100 MHz) of the first workgroup's
 // start and the last workgroup's end, and s_memtime (shader clock) over the same span of workgroup 0 -- what a launch takes
 // on the shader array itself, beside its dispatch timestamps.  No stamp executes in the product build.
+// S3_ABLATE (diagnostic builds of tools/micro/split3_phases.hip only; results are garbage): bit 0 = no global loads in the main
+// loop, bit 1 = no LDS writes, bit 2 = no barrier, bit 3 = no fragment reads -- what each part of the K loop costs beside the MFMAs
+#ifndef S3_ABLATE
+#define S3_ABLATE 0
+#endif
+#ifndef S3_DMA_VARIANT
+#define S3_DMA_VARIANT 0   // diagnostic builds: bit 0 = no sched_group_barrier in the DMA kernel's slice, bit 1 = s_setprio(1) on the younger half of the waves
+#endif
 #ifdef S3_STAMPS
 __device__ unsigned long long s3_stamps[4] = {~0ull, 0ull, 0ull, 0ull};   // min start, max end (realtime); wg 0: start, end (s_memtime)
+// per workgroup (wave 0): shader cycles summed over its tiles in {prologue, main loop, epilogue}, tiles, realtime start / end
+__device__ unsigned long long s3_wg[1024][6];
 #endif
 
 template <int WAVES_M, int WAVES_N, int BM, int BN, int NS, int KS, bool PERSIST>
@@ -174,6 +298,7 @@ void gemm_split3_kernel(S3Args g) {
   u32x4 ra[NS][3][CA], rw[NS][3][CW];
   auto issue = [&](int k0, auto set_c) __attribute__((always_inline)) {
     constexpr int S = decltype(set_c)::value;
+    if ((S3_ABLATE & 1) && k0 > 0) return;
     int ka = k0;
     if (g.conv_C) {   // wave-uniform: the tap this K stage belongs to (conv_C % (32 KS) == 0: a stage never straddles a tap)
       const int tap = k0 / g.conv_C, c0 = k0 - tap * g.conv_C, ky = tap / 3, kx = tap - 3 * ky;
@@ -189,6 +314,7 @@ void gemm_split3_kernel(S3Args g) {
   };
   auto store = [&](int buf, auto set_c) __attribute__((always_inline)) {
     constexpr int S = decltype(set_c)::value;
+    if ((S3_ABLATE & 2) && buf > 0) return;
     unsigned char *base = smem + buf * STAGE + sw;
 #pragma unroll
     for (int p = 0; p < 3; p++) {
@@ -211,12 +337,15 @@ void gemm_split3_kernel(S3Args g) {
   for (int ks = 0; ks < KS; ks++) foff[ks] = l16 * ROWB + (((4 * ks + lq) ^ swz(l16)) * 16);
   const int abase = wm * ROWB, bbase = 3 * APLANE + wn * ROWB;
   bf16x8 wf[3][BN], af[2][3];
+  bool frag_reads = true;   // S3_ABLATE bit 3: switched off after the tile prologue
   auto read_w = [&](int buf, int j, int ks) __attribute__((always_inline)) {
+    if ((S3_ABLATE & 8) && !frag_reads) return;
     const unsigned char *base = smem + buf * STAGE + bbase + j * 16 * ROWB + foff[ks];
 #pragma unroll
     for (int p = 0; p < 3; p++) wf[p][j] = *reinterpret_cast<const bf16x8 *>(base + p * WPLANE);
   };
   auto read_a = [&](int buf, int i, int set, int ks) __attribute__((always_inline)) {
+    if ((S3_ABLATE & 8) && !frag_reads) return;
     const unsigned char *base = smem + buf * STAGE + abase + i * 16 * ROWB + foff[ks];
 #pragma unroll
     for (int p = 0; p < 3; p++) af[set][p] = *reinterpret_cast<const bf16x8 *>(base + p * APLANE);
@@ -257,6 +386,12 @@ void gemm_split3_kernel(S3Args g) {
 #pragma unroll
     for (int j = BN - HB; j < BN; j++) read_w(0, j, 0);
     read_a(0, 0, 0, 0);
+    if (S3_ABLATE & 8) {   // every fragment register defined once, then no more reads
+#pragma unroll
+      for (int j = 0; j < BN; j++) read_w(0, j, 0);
+      read_a(0, 0, 1, 0);
+      frag_reads = false;
+    }
   };
   issue(0, IntC<0>{});
   // MFMA part of ONE 32-k slice (index KSI of its stage).  The slice's first fragments (Whi, A row 0) were read during the
@@ -291,7 +426,7 @@ void gemm_split3_kernel(S3Args g) {
           }
           // every LDS read of stage `cur` has been issued; the writes into `nxt` were issued at the top of the stage
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
+          if (!(S3_ABLATE & 4)) __builtin_amdgcn_s_barrier();
           if (more) {
 #pragma unroll
             for (int j = BN - HB; j < BN; j++) read_w(nxt, j, 0);   // Whi of the next slice (its registers are free now) ...
@@ -349,114 +484,25 @@ void gemm_split3_kernel(S3Args g) {
   };
 
   auto tile_epilogue = [&](int em0, int en0) __attribute__((always_inline)) {
-    // ---- epilogue: the accumulators hold C[m = block row base + l16][n = block column base + 4 lq .. + 3].  bias -> activation
-    // -> residual, as gemm.hip.  Wide path: the wave re-distributes its tile through its own LDS slice (free after the last
-    // barrier; row stride + 4 floats: conflict-free ds_write_b128) so that a store instruction writes whole row segments
-    // (16 BN floats per row), as float4 or -- when the consumer is the next GEMM -- directly as bf16x3 planes.
-    if (g.vec_epilogue) {
-      constexpr int RM = 16 * BM, CN = 16 * BN, LDW = CN + 4, LPR = CN / 4, RPI = 64 / LPR, NIT = RM / RPI;
-      float *ep = reinterpret_cast<float *>(smem) + wave * (RM * LDW);
-  #pragma unroll
-      for (int i = 0; i < BM; i++)
-  #pragma unroll
-        for (int j = 0; j < BN; j++) *reinterpret_cast<f32x4 *>(ep + (i * 16 + l16) * LDW + j * 16 + 4 * lq) = acc[i][j];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
-      const int n = en0 + wn + c4;
-      const bool colok = n < g.N;
-      const int nc = colok ? n : 0;
-      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      if (g.bias && colok) bv = *reinterpret_cast<const f32x4 *>(g.bias + n);
-      auto run = [&](auto act_c, auto res_c, auto pl_c) __attribute__((always_inline)) {
-        constexpr int ACT = decltype(act_c)::value;
-        constexpr bool HASR = decltype(res_c)::value != 0, PLANES = decltype(pl_c)::value != 0;
-        constexpr int EB = NIT < 8 ? NIT : 8;    // rows in flight between the LDS read / residual load and the store
-  #pragma unroll
-        for (int b = 0; b < NIT; b += EB) {
-          f32x4 cv[EB], rv[EB];
-  #pragma unroll
-          for (int q = 0; q < EB; ++q) {
-            const int rr = (b + q) * RPI + r0;
-            cv[q] = *reinterpret_cast<const f32x4 *>(ep + rr * LDW + c4);
-            if constexpr (HASR) rv[q] = *reinterpret_cast<const f32x4 *>(g.R + (size_t)(min(em0 + wm + rr, g.M - 1) + g.m_base) * g.ldr + nc);
-          }
-  #pragma unroll
-          for (int q = 0; q < EB; ++q) {
-            const int m = em0 + wm + (b + q) * RPI + r0;
-            f32x4 v = cv[q];
-  #pragma unroll
-            for (int t = 0; t < 4; t++) v[t] = apply_act_c<ACT>(v[t] + bv[t]);
-            if constexpr (HASR) v += rv[q];
-            if (colok && m < g.M) {
-              if constexpr (PLANES) {
-                s3_store4(g.Cp, g.c_plane, (size_t)(m + g.m_base) * g.N + n, v);
-              } else {
-                const int mm = m + g.m_base;
-                const size_t crow = g.c_seg ? (size_t)(mm / g.c_seg) * g.c_seg_stride + (mm % g.c_seg) : (size_t)mm;
-                *reinterpret_cast<f32x4 *>(g.C + crow * g.ldc + n) = v;
-              }
-            }
-          }
-        }
-      };
-      auto run_act = [&](auto act_c) __attribute__((always_inline)) {
-        if (g.Cp) {
-          if (g.R) run(act_c, IntC<1>{}, IntC<1>{});
-          else run(act_c, IntC<0>{}, IntC<1>{});
-        } else {
-          if (g.R) run(act_c, IntC<1>{}, IntC<0>{});
-          else run(act_c, IntC<0>{}, IntC<0>{});
-        }
-      };
-      switch (g.act) {
-        case ACT_GELU: run_act(IntC<ACT_GELU>{}); break;
-        case ACT_SILU: run_act(IntC<ACT_SILU>{}); break;
-        case ACT_TANH: run_act(IntC<ACT_TANH>{}); break;
-        case ACT_LRELU: run_act(IntC<ACT_LRELU>{}); break;
-        default: run_act(IntC<ACT_NONE>{}); break;
-      }
-      return;
-    }
-    // narrow path (N or the leading dimensions not float4-addressable): one dword at a time from the accumulators
-    auto run = [&](auto act_c, auto res_c) __attribute__((always_inline)) {
-      constexpr int ACT = decltype(act_c)::value;
-      constexpr bool HASR = decltype(res_c)::value != 0;
-  #pragma unroll
-      for (int j = 0; j < BN; j++) {
-        const int n = en0 + wn + j * 16 + 4 * lq;
-  #pragma unroll
-        for (int i = 0; i < BM; i++) {
-          const int m = em0 + wm + i * 16 + l16;
-          if (m >= g.M) continue;
-          const int mm = m + g.m_base;
-          const size_t crow = g.c_seg ? (size_t)(mm / g.c_seg) * g.c_seg_stride + (mm % g.c_seg) : (size_t)mm;
-  #pragma unroll
-          for (int t = 0; t < 4; t++) {
-            if (n + t < g.N) {
-              float o = apply_act_c<ACT>(acc[i][j][t] + (g.bias ? g.bias[n + t] : 0.f));
-              if constexpr (HASR) o += g.R[(size_t)mm * g.ldr + n + t];
-              g.C[crow * g.ldc + n + t] = o;
-            }
-          }
-        }
-      }
-    };
-    auto run_act = [&](auto act_c) __attribute__((always_inline)) {
-      if (g.R) run(act_c, IntC<1>{});
-      else run(act_c, IntC<0>{});
-    };
-    switch (g.act) {
-      case ACT_GELU: run_act(IntC<ACT_GELU>{}); break;
-      case ACT_SILU: run_act(IntC<ACT_SILU>{}); break;
-      case ACT_TANH: run_act(IntC<ACT_TANH>{}); break;
-      case ACT_LRELU: run_act(IntC<ACT_LRELU>{}); break;
-      default: run_act(IntC<ACT_NONE>{}); break;
-    }
+    // the wave's LDS slice: its whole 16 BM x 16 BN tile with the padded row stride (the staging buffers are free after the last barrier)
+    s3_tile_epilogue<BM, BN, 1>(g, acc, reinterpret_cast<float *>(smem) + wave * (16 * BM * (16 * BN + 4)), em0, en0, wm, wn, lane);
   };
 
+#ifdef S3_STAMPS
+  unsigned long long ph_pro = 0, ph_main = 0, ph_epi = 0, ph_tiles = 0;
+#endif
   for (;;) {
+#ifdef S3_STAMPS
+    const unsigned long long ph0 = __builtin_amdgcn_s_memtime();
+#endif
     tile_prologue();
+#ifdef S3_STAMPS
+    const unsigned long long ph1 = __builtin_amdgcn_s_memtime();
+#endif
     tile_mainloop();
+#ifdef S3_STAMPS
+    const unsigned long long ph2 = __builtin_amdgcn_s_memtime();
+#endif
     const int em0 = m0, en0 = n0;   // the tile being finished
     bool more_tiles = false;
     if constexpr (PERSIST) {
@@ -470,6 +516,21 @@ void gemm_split3_kernel(S3Args g) {
     }
     tile_epilogue(em0, en0);
 #ifdef S3_STAMPS
+    {
+      const unsigned long long ph3 = __builtin_amdgcn_s_memtime();
+      ph_pro += ph1 - ph0;
+      ph_main += ph2 - ph1;
+      ph_epi += ph3 - ph2;
+      ph_tiles++;
+    }
+    if (!more_tiles && threadIdx.x == 0 && blockIdx.x < 1024) {
+      s3_wg[blockIdx.x][0] = ph_pro;
+      s3_wg[blockIdx.x][1] = ph_main;
+      s3_wg[blockIdx.x][2] = ph_epi;
+      s3_wg[blockIdx.x][3] = ph_tiles;
+      s3_wg[blockIdx.x][4] = st_rt0;
+      s3_wg[blockIdx.x][5] = __builtin_amdgcn_s_memrealtime();
+    }
     if (!more_tiles) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left the wave
       if (threadIdx.x == 0) {
@@ -488,6 +549,234 @@ void gemm_split3_kernel(S3Args g) {
   }
 }
 
+
+// ---- The same tile arithmetic with LDS-DMA staging (global_load_lds_dwordx4: HBM/L2 -> LDS without passing the register file).
+// Round 3, from K-loop ablations of the kernel above (tools/micro/split3_phases.hip -DS3_ABLATE, profiles/round3_split3_phases.txt):
+// with the 128x256 tile the VGPR -> LDS write pass (72 ds_write_b128 per slice and workgroup, ~80 B/clk/CU through the store
+// path) cost 16 % of the launch and the register-staged loads another 10 %; MFMAs + fragment reads + the barrier alone run at
+// the chip's power ceiling.  Here a K slice of the next stage is requested straight into the other LDS stage right after the
+// barrier that frees it and awaited (vmcnt(0)) just before the next barrier: no staging registers (-36 VGPRs), no ds_write.
+//  * A 1 KiB DMA piece = 16 rows x 64 B of one plane, lane l -> LDS byte 16 l of the piece (row l >> 2, physical slot l & 3);
+//    the XOR swizzle of the fragment reads is applied on the SOURCE side: lane l fetches logical slot (l & 3) ^ swz(row).
+//  * wave w moves pieces w, w + 8, ... of each plane (A: TM / 16 pieces, W: TN / 16), i.e. (TM + TN) / 128 pieces per plane.
+//  * global addresses = wave-uniform 64-bit base (tile row 0, plane, K offset: scalar registers) + a per-lane 32-bit byte
+//    offset fixed for the whole tile (row clamp, conv halo geometry and the slot permutation live in it).
+//  * persistent walk: the next tile's first slice is requested into stage 0 BEFORE the epilogue, which therefore works in
+//    the stage-1 region only, half of a wave's tile at a time (s3_tile_epilogue<.., 2>).
+// The MFMA order per output element is the kernel's above: results are bitwise identical.
+typedef __attribute__((address_space(3))) void s3_lds_void;
+typedef __attribute__((address_space(1))) const void s3_glb_void;
+
+template <int WAVES_M, int WAVES_N, int BM, int BN, bool PERSIST>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1)
+void gemm_split3_dma_kernel(S3Args g) {
+  constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW, TM = 16 * BM * WAVES_M, TN = 16 * BN * WAVES_N;
+  constexpr int ROWB = 64;
+  constexpr int PA = TM / 16, PW = TN / 16, CA = PA / NW, CW = PW / NW;        // 1 KiB pieces per plane: of the tile / of one wave
+  static_assert(PA % NW == 0 && PW % NW == 0 && CA >= 1 && CW >= 1, "every wave moves whole pieces of both operands");
+  constexpr int APLANE = TM * ROWB, WPLANE = TN * ROWB, STAGE = 3 * (APLANE + WPLANE);
+  constexpr int HB = BN / 2;
+  static_assert(BN >= 2 && (BM % 2) == 0, "rotating fragment schedule");
+  static_assert(NW * (16 * BM / 2) * (16 * BN + 4) * 4 <= STAGE, "the two-pass epilogue must fit one staging buffer");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef S3_STAMPS
+  const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime(), st_c0 = __builtin_amdgcn_s_memtime();
+#endif
+
+  const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN, nwg = tiles_m * tiles_n;
+  int m0, n0;
+  auto locate = [&](int t) __attribute__((always_inline)) {   // XCD-aware bijective remap + grouped walk, as the kernel above
+    const int q = nwg >> 3, r = nwg & 7, xcd = t & 7, within = t >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    const int per_group = 8 * tiles_n, group = t / per_group, first_m = group * 8, gsz = min(tiles_m - first_m, 8),
+              in_group = t - group * per_group;
+    m0 = (first_m + in_group % gsz) * TM;
+    n0 = (in_group / gsz) * TN;
+    if (S3_ABLATE & 16) m0 = (S3_ABLATE & 32) ? m0 : 0, n0 = 0;   // diagnostic: bit 4 = every tile reads the operands of tile (0, 0); bits 4+5 = of tile (m, 0)
+  };
+  int tile = blockIdx.x;
+  locate(tile);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = (wave / WAVES_N) * (16 * BM), wn = (wave % WAVES_N) * (16 * BN);
+  auto swz = [](int row) __attribute__((always_inline)) {
+    const int gq = (row >> 2) & 3;
+    return (((gq ^ (gq >> 1)) & 1) << 1) | (gq >> 1);
+  };
+  // DMA source map of this lane: row (lane >> 2) of a piece, logical slot = physical slot ^ swz(row) (pieces start on multiples of 16 rows)
+  const int prow = lane >> 2, pslot = (lane & 3) ^ swz(prow);
+  unsigned voffA[CA], voffW[CW];          // byte offsets from the tile's uniform bases
+  const unsigned short *baseA, *baseW;    // uniform: plane 0, K offset 0, tile row 0
+  auto conv_off = [&](int am) __attribute__((always_inline)) {   // element offset of logical row am's top-left halo pixel
+    const int hw = g.conv_H * g.conv_W, b = am / hw, r = am - b * hw, y = r / g.conv_W, x = r - y * g.conv_W;
+    return (((size_t)b * (g.conv_H + 2) + y) * (g.conv_W + 2) + x) * g.conv_C;
+  };
+  auto setup = [&]() __attribute__((always_inline)) {
+    const size_t a0 = g.conv_C ? conv_off(min(m0, g.M - 1)) : (size_t)m0 * g.K;
+    baseA = g.A + a0;
+    baseW = g.W + (size_t)n0 * g.K;
+#pragma unroll
+    for (int i = 0; i < CA; i++) {
+      const int am = min(m0 + (wave + NW * i) * 16 + prow, g.M - 1);
+      const size_t off = g.conv_C ? conv_off(am) : (size_t)am * g.K;
+      voffA[i] = (unsigned)((off - a0) * 2 + pslot * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < CW; i++) {
+      const int wr = min(n0 + (wave + NW * i) * 16 + prow, g.N - 1);
+      voffW[i] = (unsigned)(((size_t)(wr - n0) * g.K) * 2 + pslot * 16);
+    }
+  };
+  setup();
+  // request K slice k0 of the current tile into LDS stage `buf`: 3 (CA + CW) instructions per wave
+  auto dma = [&](int k0, int buf) __attribute__((always_inline)) {
+    if ((S3_ABLATE & 1) && k0 > 0) return;
+    int ka = k0;
+    if (g.conv_C) {   // the tap this K slice belongs to (conv_C % 32 == 0: a slice never straddles a tap)
+      const int tap = k0 / g.conv_C, c0 = k0 - tap * g.conv_C, ky = tap / 3, kx = tap - 3 * ky;
+      ka = (ky * (g.conv_W + 2) + kx) * g.conv_C + c0;
+    }
+    unsigned char *stage = smem + buf * STAGE;
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+      const char *pa = reinterpret_cast<const char *>(baseA + p * g.a_plane + ka);
+      const char *pw = reinterpret_cast<const char *>(baseW + p * g.w_plane + k0);
+#pragma unroll
+      for (int i = 0; i < CA; i++)
+        __builtin_amdgcn_global_load_lds((s3_glb_void *)(pa + voffA[i]), (s3_lds_void *)(stage + p * APLANE + (wave + NW * i) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < CW; i++)
+        __builtin_amdgcn_global_load_lds((s3_glb_void *)(pw + voffW[i]), (s3_lds_void *)(stage + 3 * APLANE + p * WPLANE + (wave + NW * i) * 1024), 16, 0, 0);
+    }
+  };
+  f32x4 acc[BM][BN];
+  const int l16 = lane & 15, lq = lane >> 4;
+  const int foff = l16 * ROWB + ((lq ^ swz(l16)) * 16);
+  const int abase = wm * ROWB, bbase = 3 * APLANE + wn * ROWB;
+  bf16x8 wf[3][BN], af[2][3];
+  auto read_w = [&](int buf, int j) __attribute__((always_inline)) {
+    const unsigned char *base = smem + buf * STAGE + bbase + j * 16 * ROWB + foff;
+#pragma unroll
+    for (int p = 0; p < 3; p++) wf[p][j] = *reinterpret_cast<const bf16x8 *>(base + p * WPLANE);
+  };
+  auto read_a = [&](int buf, int i, int set) __attribute__((always_inline)) {
+    const unsigned char *base = smem + buf * STAGE + abase + i * 16 * ROWB + foff;
+#pragma unroll
+    for (int p = 0; p < 3; p++) af[set][p] = *reinterpret_cast<const bf16x8 *>(base + p * APLANE);
+  };
+  // one 16 x 16 block over a 32-k slice: the six terms, smallest first -- THE order of the arithmetic (header of this file)
+  auto block = [&](int i, int j, int set) __attribute__((always_inline)) {
+    f32x4 c = acc[i][j];
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][j], af[set][2], c, 0, 0, 0);   // a3 w1
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2][j], af[set][0], c, 0, 0, 0);   // a1 w3
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][j], af[set][1], c, 0, 0, 0);   // a2 w2
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][j], af[set][1], c, 0, 0, 0);   // a2 w1
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][j], af[set][0], c, 0, 0, 0);   // a1 w2
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][j], af[set][0], c, 0, 0, 0);   // a1 w1
+    acc[i][j] = c;
+  };
+  const int nk = g.K / 32;
+  // start of a tile: its first slice has been requested into stage 0 (here for the first tile, before the previous tile's epilogue
+  // for the following ones)
+  auto tile_prologue = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < BM; i++)
+#pragma unroll
+      for (int j = 0; j < BN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's pieces of slice 0 have landed (and its epilogue traffic is done)
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = BN - HB; j < BN; j++) read_w(0, j);
+    read_a(0, 0, 0);
+  };
+  dma(0, 0);
+  if ((S3_DMA_VARIANT & 2) && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+  // one K slice: [request slice kt + 1 into the other stage] MFMAs in the rotating order of the kernel above; the ONE barrier sits
+  // 6 BN / 2 MFMAs before the slice's end, behind this wave's vmcnt(0) (its pieces of slice kt + 1 are in LDS) and lgkmcnt(0) (its
+  // reads of the current stage are done), and the MFMAs left cover the first fragment reads of the next stage
+  auto slice = [&](int kt, bool more) __attribute__((always_inline)) {
+    const int cur = kt & 1, nxt = cur ^ 1;
+    if (more) dma((kt + 1) * 32, nxt);
+#pragma unroll
+    for (int j = 0; j < BN - HB; j++) read_w(cur, j);       // Wlo: needed after the Whi blocks of row 0
+#pragma unroll
+    for (int i = 0; i < BM; i++) {
+      const int set = i & 1;
+      if (i + 1 < BM) read_a(cur, i + 1, set ^ 1);
+#pragma unroll
+      for (int j = BN - HB; j < BN; j++) block(i, j, set);
+      if (i == BM - 1) {
+        constexpr int NMF1 = 6 * (BM * BN - (BN - HB)), NDMA = 3 * (CA + CW), NDR1 = 3 * (BN - HB) + 3 * (BM - 1);
+        if constexpr (!(S3_DMA_VARIANT & 1)) {
+#pragma unroll
+          for (int q = 0; q < NMF1; q++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (q < NDMA) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            if (q % 4 == 0 && q / 4 < NDR1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (more) {
+#pragma unroll
+          for (int j = BN - HB; j < BN; j++) read_w(nxt, j);
+          read_a(nxt, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < BN - HB; j++) block(i, j, set);
+    }
+  };
+#ifdef S3_STAMPS
+  unsigned long long ph_pro = 0, ph_main = 0, ph_epi = 0, ph_tiles = 0;
+#endif
+  for (;;) {
+#ifdef S3_STAMPS
+    const unsigned long long ph0 = __builtin_amdgcn_s_memtime();
+#endif
+    tile_prologue();
+#ifdef S3_STAMPS
+    const unsigned long long ph1 = __builtin_amdgcn_s_memtime();
+#endif
+    for (int kt = 0; kt + 1 < nk; ++kt) slice(kt, true);
+    slice(nk - 1, false);
+#ifdef S3_STAMPS
+    const unsigned long long ph2 = __builtin_amdgcn_s_memtime();
+#endif
+    const int em0 = m0, en0 = n0;
+    bool more_tiles = false;
+    if constexpr (PERSIST) {
+      tile += gridDim.x;
+      more_tiles = tile < nwg;
+      if (more_tiles) {   // every read of both stages is behind the last barrier: the next tile's first slice flies during the epilogue
+        locate(tile);
+        setup();
+        dma(0, 0);
+      }
+    }
+    // the epilogue's LDS slice lives in the stage-1 region (stage 0 may be receiving the next tile)
+    s3_tile_epilogue<BM, BN, 2>(g, acc, reinterpret_cast<float *>(smem + STAGE) + wave * ((16 * BM / 2) * (16 * BN + 4)), em0, en0, wm, wn, lane);
+#ifdef S3_STAMPS
+    {
+      const unsigned long long ph3 = __builtin_amdgcn_s_memtime();
+      ph_pro += ph1 - ph0;
+      ph_main += ph2 - ph1;
+      ph_epi += ph3 - ph2;
+      ph_tiles++;
+    }
+    if (!more_tiles && threadIdx.x == 0 && blockIdx.x < 1024) {
+      s3_wg[blockIdx.x][0] = ph_pro;
+      s3_wg[blockIdx.x][1] = ph_main;
+      s3_wg[blockIdx.x][2] = ph_epi;
+      s3_wg[blockIdx.x][3] = ph_tiles;
+      s3_wg[blockIdx.x][4] = st_rt0;
+      s3_wg[blockIdx.x][5] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+    if (!more_tiles) break;
+    // (the next tile's prologue waits for this wave's LDS traffic and meets the other waves at its barrier before stage 1 is refilled)
+  }
+}
+
 // x = x1 + x2 + x3: planes [3][rows][cols] (bf16 bit patterns).  cols % 8 == 0, 16-byte aligned rows.
 extern "C" int sgic_split3_f32(const float *d_x, int ld, int rows, int cols, int seg, int seg_stride, uint16_t *d_planes,
                                sgic_stream_t stream) {
@@ -501,7 +790,7 @@ extern "C" int sgic_split3_f32(const float *d_x, int ld, int rows, int cols, int
   return sgic::check_launch("split3_rows_kernel");
 }
 
-#define SGIC_SPLIT3_TILE_MODES 15
+#define SGIC_SPLIT3_TILE_MODES 17
 
 template <int WAVES_M, int WAVES_N, int BM, int BN, int NS, int KS = 1, bool PERSIST = false>
 static int s3_launch(const S3Args &g, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
@@ -527,18 +816,52 @@ static int s3_launch(const S3Args &g, hipStream_t st, hipEvent_t ev_start, hipEv
   return sgic::check_launch("gemm_split3_kernel");
 }
 
+template <int WAVES_M, int WAVES_N, int BM, int BN, bool PERSIST = false>
+static int s3_launch_dma(const S3Args &g, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  constexpr int NT = 64 * WAVES_M * WAVES_N, TM = 16 * BM * WAVES_M, TN = 16 * BN * WAVES_N;
+  constexpr int LDS = 2 * 3 * (TM + TN) * 64;
+  static bool attr_set[64] = {};   // per device, as s3_launch
+  auto kernel = gemm_split3_dma_kernel<WAVES_M, WAVES_N, BM, BN, PERSIST>;
+  int dev = 0;
+  SGIC_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    SGIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
+  unsigned ntiles = (unsigned)(((g.M + TM - 1) / TM) * ((g.N + TN - 1) / TN));
+  const dim3 grid(PERSIST ? (ntiles < 256u ? ntiles : 256u) : ntiles);
+  if (ev_start || ev_stop) {
+    hipExtLaunchKernelGGL(kernel, grid, dim3(NT), LDS, st, ev_start, ev_stop, 0, g);
+  } else {
+    kernel<<<grid, NT, LDS, st>>>(g);
+  }
+  return sgic::check_launch("gemm_split3_dma_kernel");
+}
+
+// Which kernel a tile mode runs (round 3, tools/micro/split3_phases.hip on the model's shapes): the 128x256 / 256x128 tiles take the
+// LDS-DMA kernel (a slice is ~3000 cycles: the DMA latency hides; 3-9 % shorter launches than register staging), the 128x128 tile
+// keeps register staging under its old numbers (its slices are half as long and long-K shapes lose ~10 % with one slice of cover)
+// and is ALSO offered with DMA staging as modes 16 / 17 for the tuner (short-K shapes gain 2-4 %).
 static int s3_mode(const S3Args &g, int mode, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+  // a DMA piece is addressed by per-lane 32-bit byte offsets from the tile's base: true for every tile below unless rows are absurdly long
+  const bool dma_ok = (size_t)g.K * 2 * 256 < (1ull << 31) && (!g.conv_C || (size_t)(g.conv_W + 2) * g.conv_C * 2 * 1024 < (1ull << 31));
   switch (mode) {
-    case 1: return s3_launch<2, 4, 4, 4, 1>(g, st, e0, e1);
+    case 1: return dma_ok ? s3_launch_dma<2, 4, 4, 4>(g, st, e0, e1) : s3_launch<2, 4, 2, 2, 1>(g, st, e0, e1);
+    case 10: return dma_ok ? s3_launch_dma<2, 4, 4, 4, true>(g, st, e0, e1) : s3_launch<2, 4, 2, 2, 1>(g, st, e0, e1);
+#ifndef S3_MICRO_BIG_ONLY   // diagnostic builds (tools/micro) instantiate the two kernels above only: minutes less of compile time
+    case 14: return dma_ok ? s3_launch_dma<4, 2, 4, 4>(g, st, e0, e1) : s3_launch<2, 4, 2, 2, 1>(g, st, e0, e1);               // 256x128: the 128x256 tile's blocking for N = 128
+    case 15: return dma_ok ? s3_launch_dma<4, 2, 4, 4, true>(g, st, e0, e1) : s3_launch<2, 4, 2, 2, 1>(g, st, e0, e1);
+    case 16: return dma_ok ? s3_launch_dma<2, 4, 4, 2>(g, st, e0, e1) : s3_launch<2, 4, 4, 2, 1>(g, st, e0, e1);
+    case 17: return dma_ok ? s3_launch_dma<2, 4, 4, 2, true>(g, st, e0, e1) : s3_launch<2, 4, 4, 2, 1, 1, true>(g, st, e0, e1);
     case 2: return s3_launch<2, 4, 4, 2, 1>(g, st, e0, e1);
+    case 11: return s3_launch<2, 4, 4, 2, 1, 1, true>(g, st, e0, e1);
     // the 32x32 latency tile: 64-k stages when K allows (and, for a convolution, a stage stays inside one tap)
     case 3: return s3_launch<2, 2, 2, 2, 4>(g, st, e0, e1);   // (64-k stages measured no better for the 64x64 tile)
     case 4: return (g.K % 64 == 0 && g.conv_C % 64 == 0) ? s3_launch<2, 2, 1, 1, 3, 2>(g, st, e0, e1) : s3_launch<2, 2, 1, 1, 6>(g, st, e0, e1);
-    case 10: return s3_launch<2, 4, 4, 4, 1, 1, true>(g, st, e0, e1);
-    case 11: return s3_launch<2, 4, 4, 2, 1, 1, true>(g, st, e0, e1);
-    case 14: return s3_launch<4, 2, 4, 4, 1>(g, st, e0, e1);               // 256x128: the 128x256 tile's blocking for N = 128
-    case 15: return s3_launch<4, 2, 4, 4, 1, 1, true>(g, st, e0, e1);
-    default: return s3_launch<2, 4, 2, 2, 1>(g, st, e0, e1);
+    default: return s3_launch<2, 4, 2, 2, 1>(g, st, e0, e1);   // 5: 64x128, two workgroups per CU
+#else
+    default: return SGIC_EINVAL;
+#endif
   }
 }
 

@@ -7,12 +7,18 @@ has to be a pipeline of its own, with bounded memory whatever the corpus size:
   1. header pass   -- `Image.open(path).size` reads the image header only (no pixel decode): every file of the shard
                       gets its geometry, and consecutive files of equal geometry are cut into batches (a batch shares
                       padding and CLIP resize geometry).  File order inside a geometry stays the sorted order.
-  2. decode        -- a thread pool (PIL releases the GIL while decoding) fills a PINNED u8 (B,H,W,3) buffer per batch.
-                      At most `depth` batches are decoded ahead of the consumer: memory is O(depth x batch), not
+  2. decode        -- JPEG batches (baseline Huffman files: what cameras and Pillow write) are decoded ON THE GPU: the thread
+                      pool only reads the file bytes and parses markers (sgic_amd.jpeg), the compressed bytes cross PCIe
+                      (~1/10 of the pixels) and csrc/jpeg.hip does Huffman decode, IDCT, chroma upsampling and colour
+                      conversion, bit-exact with Pillow.  Other files (PNG, progressive / CMYK JPEG, ...) take the host
+                      path: a thread pool (PIL releases the GIL while decoding) fills a PINNED u8 (B,H,W,3) buffer per
+                      batch.  At most `depth` batches are prepared ahead of the consumer: memory is O(depth x batch), not
                       O(shard) -- a 10 k-image shard of 1024^2 inputs costs ~100 MB per in-flight batch, not 126 GB.
-  3. H2D + convert -- the consumer copies the u8 batch to the device asynchronously on a copy stream (a quarter of the
-                      bytes of an fp32 copy) and one HIP kernel does ToTensor, *2-1, NCHW and the replicate padding
-                      (ops.u8hwc_to_f32chw_pad).  The copy of batch k+1 runs under the GPU work of batch k.
+  3. H2D + convert -- the consumer copies the batch (compressed scans, or decoded u8: a quarter of the bytes of an fp32
+                      copy) to the device asynchronously on a copy stream, the JPEG kernels run on that stream too (one
+                      wave per image, small enough to sit beside a GEMM workgroup on the same CU), and one HIP kernel
+                      does ToTensor, *2-1, NCHW and the replicate padding (ops.u8hwc_to_f32chw_pad).  Batch k+1 is
+                      prepared under the GPU work of batch k.
 """
 import os
 import queue
@@ -41,6 +47,11 @@ def decode_rgb_u8(path, out_hw3):
     out_hw3[...] = a
 
 
+def _read_bytes(path):
+    with open(path, "rb") as f:
+        return f.read()
+
+
 def plan_batches(files, sizes, batch_size):
     """-> list of (H, W, [indices into files]): one entry per batch; files of one geometry keep their order"""
     groups = {}
@@ -54,7 +65,8 @@ def plan_batches(files, sizes, batch_size):
 
 
 class Batch:
-    __slots__ = ("H", "W", "indices", "paths", "u8", "_slot", "_owner")
+    """u8: pinned (B,H,W,3) host tensor (host-decoded batch), or None when `jpeg` holds a sgic_amd.jpeg.JpegBatch to decode on the GPU"""
+    __slots__ = ("H", "W", "indices", "paths", "u8", "jpeg", "_slot", "_owner")
 
     def release(self):
         """hand the pinned buffer back (call once the H2D copy of this batch has completed)"""
@@ -70,8 +82,13 @@ class ShardLoader:
             ...; b.release()
     A decode error is re-raised in the consumer at the position of the failing batch."""
 
-    def __init__(self, files, batch_size=32, workers=None, depth=3, pin=True):
+    def __init__(self, files, batch_size=32, workers=None, depth=3, pin=True, gpu_jpeg=None):
+        """gpu_jpeg: decode baseline JPEG batches on the GPU (default: when a GPU is present; SGIC_GPU_JPEG=0 turns it off)"""
         self.files = list(files)
+        if gpu_jpeg is None:
+            gpu_jpeg = torch.cuda.is_available() and os.environ.get("SGIC_GPU_JPEG", "1") != "0"
+        self.gpu_jpeg = bool(gpu_jpeg)
+        self.gpu_batches = self.host_batches = 0
         self.batch_size, self.depth = int(batch_size), max(1, int(depth))
         self.workers = workers or min(16, max(2, (os.cpu_count() or 4)))
         self.pin = pin and torch.cuda.is_available()
@@ -112,12 +129,27 @@ class ShardLoader:
                     except queue.Empty:
                         continue
                 n = len(idxs)
-                flat = self._buffer(slot, n * h * w * 3)
-                u8 = flat[:n * h * w * 3].view(n, h, w, 3)
-                arr = u8.numpy()
-                list(self._pool.map(lambda j: decode_rgb_u8(self.files[idxs[j]], arr[j]), range(n)))
                 b = Batch()
-                b.H, b.W, b.indices, b.paths, b.u8, b._slot, b._owner = h, w, idxs, [self.files[i] for i in idxs], u8, slot, self
+                b.H, b.W, b.indices, b.paths, b.jpeg = h, w, idxs, [self.files[i] for i in idxs], None
+                if self.gpu_jpeg and all(p.lower().endswith((".jpg", ".jpeg")) for p in b.paths):
+                    from . import jpeg as J
+                    try:     # file bytes + marker parsing on the pool; the pixels never exist on the host
+                        b.jpeg = J.JpegBatch(list(self._pool.map(_read_bytes, b.paths)), pool=self._pool)
+                        if (b.jpeg.H, b.jpeg.W) != (h, w):
+                            b.jpeg = None
+                    except J.Unsupported:
+                        b.jpeg = None          # progressive / CMYK / ...: this batch takes the host decoder
+                if b.jpeg is not None:
+                    self._free.put(slot)       # no pinned pixel buffer needed
+                    b.u8, b._slot, b._owner = None, None, None
+                    self.gpu_batches += 1
+                else:
+                    flat = self._buffer(slot, n * h * w * 3)
+                    u8 = flat[:n * h * w * 3].view(n, h, w, 3)
+                    arr = u8.numpy()
+                    list(self._pool.map(lambda j: decode_rgb_u8(self.files[idxs[j]], arr[j]), range(n)))
+                    b.u8, b._slot, b._owner = u8, slot, self
+                    self.host_batches += 1
                 self._q.put(b)
             self._q.put(None)
         except BaseException as e:               # surfaces in the consumer
@@ -154,8 +186,11 @@ class DeviceIngest:
         """pad = (pl, pr, pt, pb) of compress.py:258-261 -> x (B,3,Hp,Wp) fp32 in [-1,1] on the launch stream"""
         from . import ops
         with torch.cuda.stream(self.copy_stream):
-            d = torch.empty(batch.u8.shape, dtype=torch.uint8, device=self.device)
-            d.copy_(batch.u8, non_blocking=True)
+            if batch.jpeg is not None:       # compressed bytes up, pixels decoded on the device (csrc/jpeg.hip), on the copy stream
+                d = batch.jpeg.decode(self.device, check=False)    # error codes: batch.jpeg.last_err, read by the consumer after `done`
+            else:
+                d = torch.empty(batch.u8.shape, dtype=torch.uint8, device=self.device)
+                d.copy_(batch.u8, non_blocking=True)
             done = torch.cuda.Event()
             done.record()
         cur = torch.cuda.current_stream()

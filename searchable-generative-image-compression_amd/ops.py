@@ -101,7 +101,7 @@ def _remember(key, mode, dirty=True):
     _DIRTY = _DIRTY or dirty
 
 
-_MAX_MODE = {"gemm": 15, "conv3x3": 15, "gemm3": 15, "conv3": 15, "attn": 6, "attn3": 6}   # per kind of key
+_MAX_MODE = {"gemm": 15, "conv3x3": 15, "gemm3": 17, "conv3": 17, "attn": 6, "attn3": 6}   # per kind of key
 
 
 def _load_tile_cache():
@@ -319,7 +319,7 @@ def _pick_and_launch(key, launch, big_enough, restore=None, modes=None):
 # depend on (N, K) and on the operands' kinds, never on M, so single-image and batched requests stay bitwise identical.
 PRECISION = os.environ.get("SGIC_GEMM", "split3")
 assert PRECISION in ("f32", "split3"), f"SGIC_GEMM={PRECISION!r}: expected f32 or split3"
-SPLIT3_MODES = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+SPLIT3_MODES = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17)
 _W3 = {}          # (data_ptr, N, K, ldw, version) -> (planes, w): the weight is pinned so its address cannot be reused
 _W3_BYTES = 0
 _W3_LIMIT = 24 << 30
@@ -779,7 +779,7 @@ def conv3x3(x_halo, w, bias, B, H, W, Cin, Cout, residual=None, act=ACT_NONE, ou
             launch3(tile)
         else:
             key = ("conv3", B * H * W, H, W, Cin, Cout, int(residual is not None), act)
-            if _pick_and_launch(key, launch3, B * H * W * Cout >= (1 << 20), modes=(1, 2, 3, 5, 10, 11, 14, 15)):
+            if _pick_and_launch(key, launch3, B * H * W * Cout >= (1 << 20), modes=(1, 2, 3, 5, 10, 11, 14, 15, 16, 17)):
                 return out
         if PROFILE is not None:
             PROFILE.append((2.0 * B * H * W * Cout * 9 * Cin, (B * H * W, Cout, 9 * Cin, residual is not None, act, "s3", "conv")))
@@ -934,3 +934,22 @@ def topk_rows(scores, k):
     oi = torch.empty(nq, k, device=scores.device, dtype=torch.int32)
     call("sgic_topk_rows", _p(scores), nq, n, k, _p(os_), _p(oi))
     return os_, oi
+
+
+def jpeg_decode_batch(params, scan, tabs, segs, quant, B, H, W, total_blocks, plane_bytes, max_blocks, out=None, check=True):
+    """baseline JPEG batch -> (B,H,W,3) u8 on the device (csrc/jpeg.hip; descriptors built by sgic_amd.jpeg.JpegBatch)"""
+    require_gpu()
+    dev = params.device
+    coef = torch.empty(total_blocks * 64, dtype=torch.int16, device=dev)
+    planes = torch.empty(max(16, plane_bytes), dtype=torch.uint8, device=dev)
+    if out is None:
+        out = torch.empty(B, H, W, 3, dtype=torch.uint8, device=dev)
+    assert out.shape == (B, H, W, 3) and out.dtype == torch.uint8 and out.is_contiguous()
+    err = torch.empty(B, dtype=torch.int32, device=dev)
+    call("sgic_jpeg_decode_batch", _p(params), _p(scan), _p(tabs), _p(segs), _p(quant), _p(coef), _p(planes), _p(out), _p(err), B, H, W,
+         int(max_blocks))
+    if check:
+        e = err.cpu().numpy()
+        if e.any():
+            raise RuntimeError(f"corrupt JPEG stream(s) in the batch: error codes {e.tolist()}")
+    return out, err

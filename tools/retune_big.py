@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Re-race the launch modes of the split GEMM / implicit-GEMM convolution for every LARGE shape the in-tree tile cache knows
+(after a kernel change: round 3 moved the 128x256 / 256x128 tiles to LDS-DMA staging and added modes 16 / 17).
+Durations are dispatch timestamps (ops.profile_begin / profile_end), median of `reps` launches per mode, two interleaved passes.
+Writes gpurun_out/retune_big.json = {"picks": {key: mode}, "table": {key: {mode: us}}}; merge into the in-tree cache with --merge.
+(Replaces the round-2 one-off scripts gemm_big_modes.py / conv_modes.py / gemm_shapes_modes.py.)"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "gpurun_out", "retune_big.json")
+GEMM_MODES = (1, 2, 5, 6, 7, 8, 9, 10, 11, 12, 13, 16, 17)
+CONV_MODES = (1, 2, 3, 5, 10, 11, 14, 15, 16, 17)
+
+
+def merge():
+    import sgic_amd  # noqa: F401
+    from sgic_amd import ops
+    new = json.load(open(OUT))["picks"]
+    d = json.load(open(ops._INTREE_CACHE))
+    changed = {k: (d["picks"].get(k), v) for k, v in new.items() if d["picks"].get(k) != v}
+    d["picks"].update(new)
+    with open(ops._INTREE_CACHE, "w") as f:
+        json.dump(d, f, indent=0, sort_keys=True)
+    print(f"merged {len(new)} picks, {len(changed)} changed:", changed)
+
+
+def main():
+    import torch
+    import sgic_amd  # noqa: F401
+    from sgic_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(0)
+    cache = json.load(open(ops._INTREE_CACHE))["picks"]
+    picks, table = {}, {}
+
+    def race(fn_of_mode, modes, reps=6):
+        t = {m: [] for m in modes}
+        for _ in range(2):
+            for m in modes:
+                fn_of_mode(m)
+                ops.profile_begin(4 * reps)
+                for _ in range(reps):
+                    fn_of_mode(m)
+                recs = ops.profile_end()
+                # a launch mode made of two kernels is one record spanning both
+                t[m].append(sorted(r[1] for r in recs)[len(recs) // 2] * 1e3)
+        return {m: min(v) for m, v in t.items()}
+
+    for key, old in sorted(cache.items()):
+        kind, *nums = key.split("|")
+        nums = [int(x) for x in nums]
+        if kind == "gemm3":
+            M, N, K, res, act = nums
+            if M * N < (1 << 21) or old in (3, 4):
+                continue
+            a = torch.randn(M, K, device=dev, generator=g)
+            w = torch.randn(N, K, device=dev, generator=g) * 0.03
+            b = torch.randn(N, device=dev, generator=g)
+            r = torch.randn(M, N, device=dev, generator=g) if res else None
+            ap = ops.Planes(M, K, dev)
+            ops.split3(a, out=ap.t.view(3, M, K))
+            out = torch.empty(M, N, device=dev)
+            modes = [m for m in GEMM_MODES if not (m in (1, 6, 8, 10, 12) and N < 256)]
+            t = race(lambda m: ops.gemm(ap, w, b, residual=r, act=act, out=out, tile=m, precision="split3"), modes)
+            fl = 2.0 * M * N * K
+        elif kind == "conv3":
+            M, H, W, Cin, Cout, res, act = nums
+            B = M // (H * W)
+            if M * Cout < (1 << 21) or old in (3, 4):
+                continue
+            halo = torch.zeros(B, H + 2, W + 2, Cin, device=dev)
+            halo[:, 1:-1, 1:-1] = torch.randn(B, H, W, Cin, device=dev, generator=g)
+            w = torch.randn(Cout, 9 * Cin, device=dev, generator=g) * 0.02
+            b = torch.randn(Cout, device=dev, generator=g)
+            r = torch.randn(M, Cout, device=dev, generator=g) if res else None
+            hp = ops.halo_planes_buffer(dev, B, H, W, Cin)
+            ops.split3(halo.view(-1, Cin), out=hp.t.view(3, -1, Cin))
+            out = torch.empty(M, Cout, device=dev)
+            modes = [m for m in CONV_MODES if not (m in (1, 10) and Cout < 256)]
+            t = race(lambda m: ops.conv3x3(hp, w, b, B, H, W, Cin, Cout, residual=r, act=act, out=out, tile=m, precision="split3"), modes)
+            fl = 2.0 * M * Cout * 9 * Cin
+            del halo
+        else:
+            continue
+        best = min(t, key=t.get)
+        picks[key], table[key] = best, {str(m): round(v, 1) for m, v in t.items()}
+        print(f"{key:>40}: old m{old} {t.get(old, float('nan')):7.1f} us -> m{best} {t[best]:7.1f} us  {fl / t[best] / 1e6:6.1f} TFLOP/s   "
+              + " ".join(f"m{m}={v:.0f}" for m, v in t.items()), flush=True)
+        os.makedirs(os.path.dirname(OUT), exist_ok=True)
+        json.dump({"picks": picks, "table": table}, open(OUT, "w"), indent=0)
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    merge() if "--merge" in sys.argv else main()
