@@ -307,11 +307,13 @@ int sgic_u8hwc_to_f32chw_pad(const uint8_t *d_in, float *d_out, int B, int H, in
  * default decoder (islow IDCT, fancy chroma upsampling, jdcolor tables).  The host parses markers and strips byte stuffing
  * (sgic_amd/jpeg.py); Huffman decoding, IDCT, upsampling and colour conversion run here.  d_params: B x 64 int32 descriptors,
  * d_scan: cleaned entropy-coded segments (each padded to a multiple of 2048 B), d_tabs: B x 4 lookup tables of 1424 B,
- * d_segs: restart-interval byte offsets, d_quant: u16 tables in natural order, d_coef / d_planes: workspaces,
- * d_err[b]: 0 ok / 1 invalid code / 2 missing restart segment. */
+ * d_segs: restart-interval byte offsets, d_quant: u16 tables in natural order -- these five may be device memory or PINNED host
+ * memory (the kernels then pull the compressed bytes over PCIe themselves and no H2D copy exists); d_work_params (B x 64 int32),
+ * d_work_quant (B x 256 u16), d_coef, d_planes: device workspaces; d_err[b]: 0 ok / 1 invalid code / 2 missing restart segment. */
 int sgic_jpeg_decode_batch(const int32_t *d_params, const uint8_t *d_scan, const uint8_t *d_tabs, const int32_t *d_segs,
-                           const uint16_t *d_quant, int16_t *d_coef, uint8_t *d_planes, uint8_t *d_out, int32_t *d_err, int B, int H,
-                           int W, int max_blocks, sgic_stream_t stream);
+                           const uint16_t *d_quant, int32_t *d_work_params, uint16_t *d_work_quant, int16_t *d_coef,
+                           uint8_t *d_planes, uint8_t *d_out, int32_t *d_err, int B, int H, int W, int max_blocks,
+                           sgic_stream_t stream);
 
 /* CLIP text tower front end: out[b*L+l,:] = table[ids[b,l],:] + pos[l,:] (open_clip CLIP.encode_text, reached from
  * search.py:93-97; ids outside [0,vocab) are clamped).  D multiple of 4. */

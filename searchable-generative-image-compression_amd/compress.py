@@ -156,6 +156,8 @@ def main(argv=None):
     ingest = DeviceIngest(dev)
     clip_meta = clipc.meta(ccfg.embed_dim)
     failed = None
+    host_ms = {}      # where the launching thread spends a batch (milliseconds, summed): reported in the JSON record
+    gpu_evs = []      # (start, end) events around each batch's launch-stream work
     t_start = time.perf_counter()
 
     def write_out(job):
@@ -163,7 +165,7 @@ def main(argv=None):
         h, batch, pad, copied = job
         copied.synchronize()
         if batch.jpeg is not None:            # decoded on the GPU: a corrupt entropy-coded segment shows up as an error code
-            codes = batch.jpeg.last_err.cpu().numpy()
+            codes = batch.jpeg.err_host.numpy()[:len(batch.paths)]          # pinned, filled on the copy stream ahead of `copied`
             if codes.any():
                 raise RuntimeError(f"corrupt JPEG data in {[p for p, c in zip(batch.paths, codes) if c]} (codes {codes[codes != 0].tolist()})")
         batch.release()                       # the pinned u8 buffer goes back to the decode threads
@@ -191,13 +193,33 @@ def main(argv=None):
         # two-deep pipeline: the GPU works on batch k+1 while the host packs and writes batch k, and the decode threads
         # are already filling the pinned buffers of batches k+2 .. k+1+prefetch
         pending = None
-        for batch in loader:
+        it = iter(loader)
+        batch = next(it, None)
+        tok = ingest.start(batch) if batch is not None else None               # decode / H2D of the first batch
+        while batch is not None:
+            t_a = time.perf_counter()
+            nxt = next(it, None)
+            t_b = time.perf_counter()
+            # one batch AHEAD: the next batch's GPU JPEG decode (or H2D copy) is enqueued before this batch's kernels, so it runs under them
+            ntok = ingest.start(nxt) if nxt is not None else None
             pad = get_padding_size(batch.H, batch.W, p=256)                    # compress.py:257
-            x, copied = ingest(batch, pad)                                     # u8 H2D + ToTensor*2-1 + replicate pad on the GPU
+            x, copied = ingest.finish(tok, pad)                                # ToTensor*2-1 + replicate pad on the GPU
+            t_c = time.perf_counter()
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
             h = pipe.submit(x, clip_hw=(batch.H, batch.W))   # CLIP sees the UNPADDED top-left H x W region (compress.py:266)
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            gpu_evs.append((ev0, ev1))
+            t_d = time.perf_counter()
             if pending is not None:
                 write_out(pending)
+            t_e = time.perf_counter()
+            for k, v in (("wait_loader", t_b - t_a), ("ingest", t_c - t_b), ("submit", t_d - t_c), ("write_out_incl_gpu_wait", t_e - t_d)):
+                host_ms[k] = host_ms.get(k, 0.0) + v * 1e3
+            host_ms["batches"] = host_ms.get("batches", 0) + 1
             pending = (h, batch, pad, copied)
+            batch, tok = nxt, ntok
         if pending is not None:
             write_out(pending)
         while writes:
@@ -210,6 +232,9 @@ def main(argv=None):
         io_pool.shutdown(wait=True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t_start
+    if len(gpu_evs) > 2:      # launch-stream time of a batch (first batch excluded: autotune / cold caches) and the idle time between batches
+        host_ms["gpu_launch_stream_busy"] = sum(a.elapsed_time(b) for a, b in gpu_evs[1:]) / (len(gpu_evs) - 1) * host_ms.get("batches", 1)
+        host_ms["gpu_gap_between_batches"] = sum(gpu_evs[i][1].elapsed_time(gpu_evs[i + 1][0]) for i in range(1, len(gpu_evs) - 1)) / max(1, len(gpu_evs) - 2) * host_ms.get("batches", 1)
 
     # every rank reaches this point, failed or not: the error flag travels first so that nobody blocks in the gather
     if distributed:
@@ -232,6 +257,8 @@ def main(argv=None):
         print(json.dumps({"cli_images_per_s": round(float(rate.item()), 2), "images": len(files), "n_gpus": world,
                           "collectives": (dist.get_backend() if distributed else None),
                           "seconds_rank0": round(dt, 3), "batch_size": args.batch_size,
+                          "host_ms_per_batch": {k: round(v / max(1, host_ms.get("batches", 1)), 2) for k, v in host_ms.items() if k != "batches"},
+                          "gpu_jpeg_batches": getattr(loader, "gpu_batches", 0), "host_decoded_batches": getattr(loader, "host_batches", 0),
                           "note": "files -> .c2df: header pass, JPEG/PNG decode, H2D, encoder+entropy+CLIP, container + .npy writes"}),
               flush=True)
     ops.save_tile_cache()

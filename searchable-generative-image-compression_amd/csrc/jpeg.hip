@@ -8,7 +8,7 @@
 // Three kernels over a batch:
 //   jpeg_huff_kernel      one wave per image.  The entropy-coded segment is a serial bit stream, so the wave runs the decode loop as
 //                         wave-uniform code (every lane computes the same state -- the cost of one lane) and uses its 64 lanes for
-//                         what IS parallel: streaming the scan through an 8 KiB LDS ring in 2 KiB coalesced chunks, zeroing /
+//                         what IS parallel: streaming the scan through a 4 KiB LDS ring in 1 KiB coalesced chunks, zeroing /
 //                         storing each 64-coefficient block (lane = coefficient), holding the lookup tables in LDS.
 //   jpeg_idct_kernel      one thread per 8x8 block: dequantise, two 1-D passes of the LL&M integer IDCT, range limit -> u8 planes.
 //   jpeg_color_kernel     one thread per output pixel: chroma upsampling of the 4:4:4 / 4:2:2 / 4:2:0 / 4:4:0 layouts + colour
@@ -19,8 +19,8 @@
 #define JPG_NP 64            // int32 parameters per image (sgic_amd/jpeg.py: PARAM_*)
 #define JPG_LOOK 9           // bits of the fast Huffman lookup
 #define JPG_TAB_BYTES 1424   // one table: u16 fast[512] | i32 maxcode[18] | i32 valoff[17] | pad 4 | u8 huffval[256]
-#define JPG_RING 8192     // LDS: ring 8 KiB + tables 5.6 KiB: the wave fits BESIDE a 144 KiB GEMM workgroup on the same CU
-#define JPG_CHUNK 2048
+#define JPG_RING 4096     // LDS: ring 4 KiB + tables 5.6 KiB = 9.9 KiB: the wave fits BESIDE a 144 KiB GEMM workgroup on the same CU
+#define JPG_CHUNK 1024
 
 enum {
   P_SCAN_OFF = 0, P_SCAN_LEN, P_TAB_OFF, P_QUANT_OFF, P_NCOMP, P_W, P_H, P_HMAX, P_VMAX, P_MCUS_X, P_MCUS_Y, P_RESTART, P_SEG_OFF, P_NSEG,
@@ -33,14 +33,24 @@ __constant__ unsigned char jpg_natural[80] = {0,  1,  8,  16, 9,  2,  3,  10, 17
                                               39, 46, 53, 60, 61, 54, 47, 55, 62, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63};
 
 // ---- Huffman decode: one wave per image -------------------------------------------------------------------------------------------
+// params / scan / tabs / segs / quant_in may live in PINNED HOST memory (the kernel pulls them over PCIe: a batch is ~1 MB, read once,
+// in coalesced 1 KiB chunks) -- there is then no H2D copy to schedule; the descriptors and quantisation tables the two later kernels
+// need are left in device memory (params_dev, quant_dev) by this one.
 __global__ __launch_bounds__(64) void jpeg_huff_kernel(const int *__restrict__ params, const unsigned char *__restrict__ scan,
                                                        const unsigned char *__restrict__ tabs, const int *__restrict__ segs,
-                                                       short *__restrict__ coef, int *__restrict__ err) {
+                                                       const unsigned short *__restrict__ quant_in, int *__restrict__ params_dev,
+                                                       unsigned short *__restrict__ quant_dev, short *__restrict__ coef,
+                                                       int *__restrict__ err) {
   __shared__ __attribute__((aligned(16))) unsigned char ring[JPG_RING];
   __shared__ __attribute__((aligned(16))) unsigned char tab[4 * JPG_TAB_BYTES];
   __shared__ short blk[64];
   const int img = blockIdx.x, lane = threadIdx.x;
-  const int *P = params + (size_t)img * JPG_NP;
+  __shared__ int Ps[JPG_NP];
+  Ps[lane] = params[(size_t)img * JPG_NP + lane];
+  params_dev[(size_t)img * JPG_NP + lane] = Ps[lane];
+  __syncthreads();
+  const int *P = Ps;
+  for (int i = lane; i < 256; i += 64) quant_dev[(size_t)img * 256 + i] = quant_in[P[P_QUANT_OFF] + i];
   const unsigned char *src = scan + P[P_SCAN_OFF];
   const int total = P[P_SCAN_LEN];   // bytes, padded by the host to a multiple of JPG_CHUNK with zeros
   {
@@ -238,7 +248,7 @@ __global__ void jpeg_idct_kernel(const int *__restrict__ params, const short *__
     const int *C = P + P_COMP0 + c * P_CSTRIDE;
     const int bw = C[5], by = local / bw, bx = local - by * bw;
     const short *cf = coef + ((size_t)C[9] + local) * 64;
-    const unsigned short *q = quant + P[P_QUANT_OFF] + C[2] * 64;
+    const unsigned short *q = quant + (size_t)img * 256 + C[2] * 64;   // quant_dev of jpeg_huff_kernel: image-major
     int ws[64];
     // pass 1: columns
 #pragma unroll
@@ -328,20 +338,23 @@ __global__ void jpeg_color_kernel(const int *__restrict__ params, const unsigned
 //   multiple of 2048 bytes), d_tabs B x 4 Huffman tables (dc0, dc1, ac0, ac1) of 1424 bytes, d_segs the restart-interval byte offsets,
 //   d_quant u16 quantisation tables in natural order, d_coef / d_planes workspaces (total_blocks * 64 int16 / plane_bytes u8),
 //   d_err B int32 (0 ok, 1 invalid Huffman code, 2 missing restart segment).  max_blocks = the largest per-image block count.
+//   The five input arrays may be device memory or device-accessible PINNED host memory (no copy is then needed at all);
+//   d_work_params (B x 64 int32) / d_work_quant (B x 256 u16): device scratch for the copies the later kernels read.
 extern "C" int sgic_jpeg_decode_batch(const int32_t *d_params, const uint8_t *d_scan, const uint8_t *d_tabs, const int32_t *d_segs,
-                                      const uint16_t *d_quant, int16_t *d_coef, uint8_t *d_planes, uint8_t *d_out, int32_t *d_err, int B,
-                                      int H, int W, int max_blocks, sgic_stream_t stream) {
-  SGIC_REQUIRE(d_params && d_scan && d_tabs && d_segs && d_quant && d_coef && d_planes && d_out && d_err, "null");
+                                      const uint16_t *d_quant, int32_t *d_work_params, uint16_t *d_work_quant, int16_t *d_coef,
+                                      uint8_t *d_planes, uint8_t *d_out, int32_t *d_err, int B, int H, int W, int max_blocks,
+                                      sgic_stream_t stream) {
+  SGIC_REQUIRE(d_params && d_scan && d_tabs && d_segs && d_quant && d_work_params && d_work_quant && d_coef && d_planes && d_out && d_err, "null");
   SGIC_REQUIRE(B > 0 && H > 0 && W > 0 && max_blocks > 0, "shape");
   SGIC_REQUIRE((((uintptr_t)d_scan | (uintptr_t)d_tabs | (uintptr_t)d_planes) & 15) == 0, "16-byte alignment");
   hipStream_t st = to_stream(stream);
-  jpeg_huff_kernel<<<B, 64, 0, st>>>(d_params, d_scan, d_tabs, d_segs, d_coef, d_err);
+  jpeg_huff_kernel<<<B, 64, 0, st>>>(d_params, d_scan, d_tabs, d_segs, d_quant, d_work_params, d_work_quant, d_coef, d_err);
   int rc = sgic::check_launch("jpeg_huff_kernel");
   if (rc) return rc;
-  jpeg_idct_kernel<<<dim3(cdiv(max_blocks, 64), B), 64, 0, st>>>(d_params, d_coef, d_quant, d_planes, max_blocks);
+  jpeg_idct_kernel<<<dim3(cdiv(max_blocks, 64), B), 64, 0, st>>>(d_work_params, d_coef, d_work_quant, d_planes, max_blocks);
   rc = sgic::check_launch("jpeg_idct_kernel");
   if (rc) return rc;
   const long px = (long)H * W;
-  jpeg_color_kernel<<<dim3((unsigned)min((px + 255) / 256, 4096L), B), 256, 0, st>>>(d_params, d_planes, d_out, H, W);
+  jpeg_color_kernel<<<dim3((unsigned)min((px + 255) / 256, 4096L), B), 256, 0, st>>>(d_work_params, d_planes, d_out, H, W);
   return sgic::check_launch("jpeg_color_kernel");
 }

@@ -96,7 +96,7 @@ class ShardLoader:
         self.sizes = list(self._pool.map(image_size, self.files))                 # header pass, no pixel decode
         self.plan = plan_batches(self.files, self.sizes, self.batch_size)
         self._free = queue.Queue()
-        for s in range(self.depth + 2):      # the consumer holds up to two batches (GPU in flight + being written out)
+        for s in range(self.depth + 3):      # the consumer holds up to three batches (decoding ahead + GPU in flight + being written out)
             self._free.put(s)
         self._slots = {}
         self._q = queue.Queue(maxsize=self.depth)
@@ -111,6 +111,8 @@ class ShardLoader:
         """slot-owned flat pinned buffer, grown on demand; a batch views its first B*H*W*3 bytes"""
         t = self._slots.get(slot)
         if t is None or t.numel() < nbytes:
+            # grown with headroom: pinning is a device-synchronising allocation, and compressed batches differ in size by a few percent
+            nbytes = (int(nbytes * 1.5) + (1 << 20) - 1) & ~((1 << 20) - 1) if t is not None or self.gpu_jpeg else nbytes
             t = torch.empty(nbytes, dtype=torch.uint8)
             if self.pin:
                 t = t.pin_memory()
@@ -134,14 +136,14 @@ class ShardLoader:
                 if self.gpu_jpeg and all(p.lower().endswith((".jpg", ".jpeg")) for p in b.paths):
                     from . import jpeg as J
                     try:     # file bytes + marker parsing on the pool; the pixels never exist on the host
-                        b.jpeg = J.JpegBatch(list(self._pool.map(_read_bytes, b.paths)), pool=self._pool)
+                        b.jpeg = J.JpegBatch(list(self._pool.map(_read_bytes, b.paths)), pool=self._pool,
+                                             alloc=lambda nbytes: self._buffer(slot, nbytes))   # the slot's pinned buffer: one async H2D copy
                         if (b.jpeg.H, b.jpeg.W) != (h, w):
                             b.jpeg = None
                     except J.Unsupported:
                         b.jpeg = None          # progressive / CMYK / ...: this batch takes the host decoder
                 if b.jpeg is not None:
-                    self._free.put(slot)       # no pinned pixel buffer needed
-                    b.u8, b._slot, b._owner = None, None, None
+                    b.u8, b._slot, b._owner = None, slot, self     # the slot returns with release(), after the copy has completed
                     self.gpu_batches += 1
                 else:
                     flat = self._buffer(slot, n * h * w * 3)
@@ -176,25 +178,42 @@ class ShardLoader:
 
 
 class DeviceIngest:
-    """u8 batch -> padded fp32 NCHW on the device: async H2D on a copy stream + the fused convert/pad kernel"""
+    """batch -> padded fp32 NCHW on the device.  Two steps so that a driver can run one batch ahead:
+        tok = start(batch)        enqueue, on the copy stream, the GPU JPEG decode (compressed bytes are read in place from pinned host
+                                  memory) or the async H2D copy of a host-decoded u8 batch; returns at once
+        x, done = finish(tok, pad)  on the launch stream: wait for `tok`, then the fused ToTensor / *2-1 / NCHW / replicate-pad kernel
+    ORDER MATTERS: HIP streams can share a hardware queue, where packets launch in enqueue order -- a decode enqueued behind the ~750
+    kernels of a batch starts when that batch ends (measured: a 10 ms bubble per batch), one enqueued BEFORE them runs under them.
+    compress.py therefore calls start(batch k+1) before it submits batch k.  __call__ = start + finish."""
 
     def __init__(self, device):
         self.device = torch.device(device)
         self.copy_stream = torch.cuda.Stream(device=self.device)
 
-    def __call__(self, batch, pad):
-        """pad = (pl, pr, pt, pb) of compress.py:258-261 -> x (B,3,Hp,Wp) fp32 in [-1,1] on the launch stream"""
-        from . import ops
+    def start(self, batch):
         with torch.cuda.stream(self.copy_stream):
-            if batch.jpeg is not None:       # compressed bytes up, pixels decoded on the device (csrc/jpeg.hip), on the copy stream
-                d = batch.jpeg.decode(self.device, check=False)    # error codes: batch.jpeg.last_err, read by the consumer after `done`
+            if batch.jpeg is not None:
+                d = batch.jpeg.decode(self.device, check=False)
+                # the per-image error codes come back on THIS stream into the pinned staging buffer, ahead of `done`: the consumer
+                # reads them on the host after done.synchronize() -- a .cpu() on the launch stream would queue behind the next
+                # batch's kernels and stall the pipeline for a whole batch
+                batch.jpeg.err_host.copy_(batch.jpeg.last_err, non_blocking=True)
             else:
                 d = torch.empty(batch.u8.shape, dtype=torch.uint8, device=self.device)
                 d.copy_(batch.u8, non_blocking=True)
             done = torch.cuda.Event()
             done.record()
+        return d, done
+
+    def finish(self, tok, pad):
+        """pad = (pl, pr, pt, pb) of compress.py:258-261 -> x (B,3,Hp,Wp) fp32 in [-1,1] on the launch stream"""
+        from . import ops
+        d, done = tok
         cur = torch.cuda.current_stream()
         cur.wait_event(done)
         d.record_stream(cur)
         x = ops.u8hwc_to_f32chw_pad(d, *pad)
         return x, done
+
+    def __call__(self, batch, pad):
+        return self.finish(self.start(batch), pad)

@@ -198,9 +198,14 @@ def parse(data):
 
 
 class JpegBatch:
-    """host-side descriptor of a batch of equal-geometry JPEGs, ready for one H2D copy per array and one decode call"""
+    """host-side descriptor of a batch of equal-geometry JPEGs: ONE contiguous blob
+        params (B x 64 i32) | restart offsets (i32) | quant tables (B x 256 u16) | Huffman lookup tables (B x 4 x 1424 B) | cleaned scans
+    so that the batch crosses PCIe in a single copy.  `alloc(nbytes) -> uint8 torch tensor` supplies the staging memory: the ingest
+    passes PINNED slot buffers -- a copy from pageable memory is synchronous in HIP and, measured in the CLI trace, waited for the
+    previous batch's GPU work (the decode then ran alone instead of under it)."""
 
-    def __init__(self, datas, pool=None):
+    def __init__(self, datas, pool=None, alloc=None):
+        import torch
         ps = list(pool.map(parse, datas)) if pool is not None else [parse(d) for d in datas]
         self.last_err = None
         H, W = ps[0].H, ps[0].W
@@ -208,15 +213,30 @@ class JpegBatch:
             raise ValueError("a JPEG batch shares one geometry")
         B = len(ps)
         self.B, self.H, self.W = B, H, W
-        params = np.zeros((B, NP), dtype=np.int32)
-        scans, segs = [], []
+        nseg = sum(len(p.segs) for p in ps)
+        scan_len = [len(p.scan) + ((-len(p.scan)) % CHUNK or (CHUNK if len(p.scan) == 0 else 0)) for p in ps]
+        al = lambda n: (n + 255) & ~255
+        self.off_params, n = 0, al(B * NP * 4)
+        self.off_segs, n = n, n + al(nseg * 4)
+        self.off_quant, n = n, n + al(B * 256 * 2)
+        self.off_tabs, n = n, n + al(B * 4 * TAB_BYTES)
+        self.off_scan, n = n, n + sum(scan_len)
+        self.nseg, self.nbytes = nseg, n
+        blob = alloc(n + al(4 * B)) if alloc is not None else torch.empty(n + al(4 * B), dtype=torch.uint8)
+        self.blob = blob[:n]
+        self.err_host = blob[n:n + 4 * B].view(torch.int32)     # the error codes come back into the same (pinned) staging buffer
+        host = self.blob.numpy()
+        host[:self.off_scan] = 0
+        params = host[self.off_params:self.off_params + B * NP * 4].view(np.int32).reshape(B, NP)
+        segs = host[self.off_segs:self.off_segs + nseg * 4].view(np.int32)
+        quant = host[self.off_quant:self.off_quant + B * 512].view(np.uint16).reshape(B, 256)
+        tabs = host[self.off_tabs:self.off_tabs + B * 4 * TAB_BYTES].reshape(B, 4 * TAB_BYTES)
+        scan = host[self.off_scan:]
         scan_off = seg_off = blk_off = plane_off = 0
         self.max_blocks = 0
         for b, p in enumerate(ps):
-            pad = (-len(p.scan)) % CHUNK or (CHUNK if len(p.scan) == 0 else 0)
-            s = np.concatenate([p.scan, np.zeros(pad, dtype=np.uint8)])
             r = params[b]
-            r[P_SCAN_OFF], r[P_SCAN_LEN], r[P_TAB_OFF], r[P_QUANT_OFF] = scan_off, len(s), b * 4 * TAB_BYTES, b * 256
+            r[P_SCAN_OFF], r[P_SCAN_LEN], r[P_TAB_OFF], r[P_QUANT_OFF] = scan_off, scan_len[b], b * 4 * TAB_BYTES, b * 256
             r[P_NCOMP], r[P_W], r[P_H], r[P_HMAX], r[P_VMAX] = p.ncomp, W, H, p.hmax, p.vmax
             r[P_MCUS_X], r[P_MCUS_Y], r[P_RESTART], r[P_SEG_OFF], r[P_NSEG] = p.mcus_x, p.mcus_y, p.restart, seg_off, len(p.segs)
             nblk = 0
@@ -227,15 +247,14 @@ class JpegBatch:
                 plane_off += (d["bw"] * 8 * d["bh"] * 8 + 15) & ~15
             self.max_blocks = max(self.max_blocks, nblk)
             blk_off += nblk
-            scans.append(s)
-            segs.append(p.segs)
-            scan_off += len(s)
+            scan[scan_off:scan_off + len(p.scan)] = p.scan
+            scan[scan_off + len(p.scan):scan_off + scan_len[b]] = 0
+            segs[seg_off:seg_off + len(p.segs)] = p.segs
+            quant[b] = p.quant.reshape(-1)
+            tabs[b] = p.tabs.reshape(-1)
+            scan_off += scan_len[b]
             seg_off += len(p.segs)
-        self.params = params
-        self.scan = np.concatenate(scans)
-        self.segs = np.concatenate(segs).astype(np.int32)
-        self.tabs = np.stack([p.tabs for p in ps]).reshape(-1)
-        self.quant = np.stack([p.quant for p in ps]).reshape(-1)
+        self.params, self.tabs, self.scan = params, tabs.reshape(-1), scan     # host views (tests)
         self.total_blocks, self.plane_bytes = blk_off, plane_off
 
     def decode(self, device, out=None, check=True):
@@ -243,9 +262,21 @@ class JpegBatch:
         check=False leaves the per-image error codes in self.last_err (device int32 tensor) for the caller to read later"""
         import torch
         from . import ops
+        # a PINNED blob is read by the kernels in place (device-accessible host memory: no H2D copy to schedule -- an SDMA copy would
+        # queue behind the previous batch's result copies and start the decode only when that batch has finished); else one copy
         dev = torch.device(device)
-        up = lambda a: torch.from_numpy(a).to(dev, non_blocking=True)
-        params, scan, tabs, segs, quant = up(self.params), up(self.scan), up(self.tabs), up(self.segs), up(self.quant)
-        out, self.last_err = ops.jpeg_decode_batch(params, scan, tabs, segs, quant, self.B, self.H, self.W, self.total_blocks,
+        with torch.cuda.device(dev):
+            return self._decode(self.blob if self.blob.is_pinned() else self.blob.to(dev, non_blocking=True), out, check)
+
+    def _decode(self, d, out, check):
+        from . import ops
+        B = self.B
+        view = lambda off, nbytes: d[off:off + nbytes]
+        params = view(self.off_params, B * NP * 4)
+        segs = view(self.off_segs, max(4, self.nseg * 4))
+        quant = view(self.off_quant, B * 512)
+        tabs = view(self.off_tabs, B * 4 * TAB_BYTES)
+        scan = d[self.off_scan:]
+        out, self.last_err = ops.jpeg_decode_batch(params, scan, tabs, segs, quant, B, self.H, self.W, self.total_blocks,
                                                    self.plane_bytes, self.max_blocks, out=out, check=check)
         return out

@@ -939,15 +939,17 @@ def topk_rows(scores, k):
 def jpeg_decode_batch(params, scan, tabs, segs, quant, B, H, W, total_blocks, plane_bytes, max_blocks, out=None, check=True):
     """baseline JPEG batch -> (B,H,W,3) u8 on the device (csrc/jpeg.hip; descriptors built by sgic_amd.jpeg.JpegBatch)"""
     require_gpu()
-    dev = params.device
+    dev = torch.device("cuda", torch.cuda.current_device()) if not params.is_cuda else params.device   # inputs may be pinned host memory
     coef = torch.empty(total_blocks * 64, dtype=torch.int16, device=dev)
+    wparams = torch.empty(B * 64, dtype=torch.int32, device=dev)
+    wquant = torch.empty(B * 256, dtype=torch.int16, device=dev)
     planes = torch.empty(max(16, plane_bytes), dtype=torch.uint8, device=dev)
     if out is None:
         out = torch.empty(B, H, W, 3, dtype=torch.uint8, device=dev)
     assert out.shape == (B, H, W, 3) and out.dtype == torch.uint8 and out.is_contiguous()
     err = torch.empty(B, dtype=torch.int32, device=dev)
-    call("sgic_jpeg_decode_batch", _p(params), _p(scan), _p(tabs), _p(segs), _p(quant), _p(coef), _p(planes), _p(out), _p(err), B, H, W,
-         int(max_blocks))
+    call("sgic_jpeg_decode_batch", _p(params), _p(scan), _p(tabs), _p(segs), _p(quant), _p(wparams), _p(wquant), _p(coef), _p(planes), _p(out),
+         _p(err), B, H, W, int(max_blocks))
     if check:
         e = err.cpu().numpy()
         if e.any():

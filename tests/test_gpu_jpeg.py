@@ -55,8 +55,7 @@ def test_corrupt_scan_is_reported_not_decoded_silently():
     Image.fromarray(jpeg_cases.natural_like(64, 64, rng)).save(buf, "JPEG", quality=90, optimize=True)
     good = buf.getvalue()
     b = J.JpegBatch([good, good])
-    b.tabs = b.tabs.copy()
-    b.tabs[4 * J.TAB_BYTES:5 * J.TAB_BYTES] = 0                 # image 1: an empty DC table -> every code is invalid
+    b.tabs[4 * J.TAB_BYTES:5 * J.TAB_BYTES] = 0                 # image 1 (a view into the batch blob): an empty DC table -> every code is invalid
     with pytest.raises(RuntimeError):
         b.decode("cuda:0")
     out = b.decode("cuda:0", check=False)
