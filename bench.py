@@ -209,7 +209,7 @@ def rehearse_cpu(args, world, rank):
 
 
 # ------------------------------------------------------------------------------------------------ roofline helpers
-def by_shape_table(prof, ops, dev, top=10, pmc_shapes="round2_pmc_gemm_by_shape.json"):
+def by_shape_table(prof, ops, dev, top=10, pmc_shapes="round3_pmc_gemm_by_shape.json"):
     """per-shape roofline of the GEMM launches from the per-launch event pairs of the timed region; `frac` is against the
     peak of the kernel the shape ran on (split GEMM: bf16 peak / 6; fp32 MFMA kernel: 157.3)"""
     agg = {}
@@ -267,7 +267,7 @@ def roofline_block(prof, ops, dev, dt, steps, flops_per_step, pmc_file, pmc_shap
             traffic = int((pj["hbm_fetch_MB_per_launch_x2_corrected"] + pj["hbm_write_MB_per_launch"]) * 1e6)
     except Exception:
         pass
-    blk = {"bound": "mfma", "kernel": "gemm_split3_kernel" if dom_s3 else "gemm_f32_kernel", "achieved": round(achieved, 2), "peak": peak,
+    blk = {"bound": "mfma", "kernel": "gemm_split3_dma_kernel (+ gemm_split3_kernel for the small tiles)" if dom_s3 else "gemm_f32_kernel", "achieved": round(achieved, 2), "peak": peak,
            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
            "traffic_unit": f"bytes per launch (rocprofv3 PMC, profiles/{pmc_file})",
            "launches_per_step": n_launch // max(1, steps),
@@ -435,7 +435,8 @@ def main():
     dt_local = dt = time.perf_counter() - t0
     prof = ops.profile_end()      # [(flops, ms, shape key)] per launch of the timed region
     if rank == 0 and os.environ.get("SGIC_BENCH_SHAPES"):   # launch-ordered shape list (tools/pmc_by_shape.py joins it with PMC rows)
-        json.dump([[list(k) if isinstance(k, tuple) else k, fl, ms, ops.tile_of(k, dev)] for fl, ms, k in prof], open(os.environ["SGIC_BENCH_SHAPES"], "w"))
+        tiles = list(ops.PROFILE_TILES) if len(ops.PROFILE_TILES) == len(prof) else [ops.tile_of(k, dev) for _, _, k in prof]   # the mode each launch really took
+        json.dump([[list(k) if isinstance(k, tuple) else k, fl, ms, t] for (fl, ms, k), t in zip(prof, tiles)], open(os.environ["SGIC_BENCH_SHAPES"], "w"))
     gather_ms = sum(a.elapsed_time(b) for a, b in gather_events)
     per_rank = [(dt_local, gather_ms)]
     if world > 1:
@@ -468,7 +469,7 @@ def main():
             "per_rank_images_per_s": [round(B * args.steps / p[0], 2) for p in per_rank],
             "allgather_ms_per_step": [round(p[1] / args.steps, 4) for p in per_rank],
             "roofline": roofline_block(prof, ops, dev, dt, args.steps, gflop * 1e9 * B,
-                                       "round2_pmc_decompress_gemm_summary.json" if dec_primary else "round2_pmc_gemm_summary.json"),
+                                       "round3_pmc_decompress_gemm_summary.json" if dec_primary else "round3_pmc_gemm_summary.json"),
         }
         if world == 1 and not dec_primary and not args.no_secondary:
             # secondary line (configs[2]): the decompress path on the same process, a few steps, its own profile window
@@ -490,7 +491,7 @@ def main():
                 "ms_per_step": round(ddt / args.secondary_steps * 1e3, 3),
                 "roofline": roofline_block(dprof, ops, dev, ddt, args.secondary_steps,
                                            GFLOP_PER_IMAGE_DEC * (S / 256.0) ** 2 * 1e9 * B,
-                                           "round2_pmc_decompress_gemm_summary.json")}}
+                                           "round3_pmc_decompress_gemm_summary.json")}}
         if world == 1 and not dec_primary and not args.no_secondary and ops.PRECISION == "split3":
             # the same compress step with every GEMM on the exact-fp32 MFMA kernel (SGIC_GEMM=f32), for reference
             ops.set_precision("f32")
@@ -513,8 +514,8 @@ def main():
                 "metric": "images/sec end-to-end compress at 256x256 with SGIC_GEMM=f32 (every GEMM on v_mfma_f32_32x32x2_f32)",
                 "value": round(B * args.secondary_steps / fdt, 3), "unit": "images/s", "steps": args.secondary_steps,
                 "ms_per_step": round(fdt / args.secondary_steps * 1e3, 3),
-                "roofline": roofline_block(fprof, ops, dev, fdt, args.secondary_steps, gflop * 1e9 * B, "round2_pmc_f32_gemm_summary.json",
-                                           "round2_pmc_f32_gemm_by_shape.json")}
+                "roofline": roofline_block(fprof, ops, dev, fdt, args.secondary_steps, gflop * 1e9 * B, "round3_pmc_f32_gemm_summary.json",
+                                           "round3_pmc_f32_gemm_by_shape.json")}
         if world == 1 and not args.small:
             # live check of the claim behind `arithmetic`: rms error of a K = 4096 GEMM against an fp64 product, split GEMM vs the
             # exact-fp32 MFMA GEMM on the same operands (measurement only: the fp64 product is a torch matmul, not the product path)

@@ -37,6 +37,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define AT_KT 32      // keys per tile
+#define AT_LOG2E 1.4426950408889634f
+// S3 variant: the running maximum is only raised (and O / l rescaled) when some row's maximum grew by more than this many powers of
+// two; until then P = exp2(s - m_run) may exceed 1 (up to 2^AT_DEFER), which costs nothing in accuracy here -- P is split into three
+// bf16 pieces EXACTLY and accumulated in fp32.  The decision is one __any() per tile over the wave's 32 rows, all of ONE (unit, row
+// block) item, so a row's arithmetic depends on its item only: batch-invariant like everything else.
+#define AT_DEFER 6.0f
 #define AT_LDK 68     // padded row stride (floats) of the K tile: 272 B -> conflict-free ds_read_b128
 #define AT_LDV 64
 #define AT_TILE (AT_KT * AT_LDK + AT_KT * AT_LDV)   // floats of one unit's K+V tile (16.5 KiB)
@@ -238,10 +244,12 @@ __global__ __launch_bounds__(256, (NBUF * UP >= 4 || (S3 && UP > 1)) ? 2 : 3) vo
         const f32x4 v0 = *reinterpret_cast<const f32x4 *>(qp + 16 * c + 8 * lh), v1 = *reinterpret_cast<const f32x4 *>(qp + 16 * c + 8 * lh + 4);
         at_u32x4 p1, p2, p3;
         unsigned a0, b0, c0;
-        s3_split_pair(v0[0] * a.scale, v0[1] * a.scale, a0, b0, c0); p1[0] = a0, p2[0] = b0, p3[0] = c0;
-        s3_split_pair(v0[2] * a.scale, v0[3] * a.scale, a0, b0, c0); p1[1] = a0, p2[1] = b0, p3[1] = c0;
-        s3_split_pair(v1[0] * a.scale, v1[1] * a.scale, a0, b0, c0); p1[2] = a0, p2[2] = b0, p3[2] = c0;
-        s3_split_pair(v1[2] * a.scale, v1[3] * a.scale, a0, b0, c0); p1[3] = a0, p2[3] = b0, p3[3] = c0;
+        // S3: scores live in the LOG2 domain -- q carries scale * log2(e), so the softmax below is exp2 (v_exp_f32) with no multiply
+        const float qs = a.scale * AT_LOG2E;
+        s3_split_pair(v0[0] * qs, v0[1] * qs, a0, b0, c0); p1[0] = a0, p2[0] = b0, p3[0] = c0;
+        s3_split_pair(v0[2] * qs, v0[3] * qs, a0, b0, c0); p1[1] = a0, p2[1] = b0, p3[1] = c0;
+        s3_split_pair(v1[0] * qs, v1[1] * qs, a0, b0, c0); p1[2] = a0, p2[2] = b0, p3[2] = c0;
+        s3_split_pair(v1[2] * qs, v1[3] * qs, a0, b0, c0); p1[3] = a0, p2[3] = b0, p3[3] = c0;
         q3[c][0] = __builtin_bit_cast(at_bf16x8, p1);
         q3[c][1] = __builtin_bit_cast(at_bf16x8, p2);
         q3[c][2] = __builtin_bit_cast(at_bf16x8, p3);
@@ -349,26 +357,29 @@ __global__ __launch_bounds__(256, (NBUF * UP >= 4 || (S3 && UP > 1)) ? 2 : 3) vo
 
   // one tile of this wave's item: S^T, online softmax, O^T update, reading region `reg`
   auto compute_s = [&](const float *sK, f32x16 &s) {
-    f32x16 sb;
-#pragma unroll
-    for (int e = 0; e < 16; e++) s[e] = 0.f, sb[e] = 0.f;
     if constexpr (S3) {
-      // four 16-d steps, six bf16 MFMAs each (terms smallest first, as gemm_split.hip); steps alternate between two accumulators
+      // four 16-d steps, six bf16 MFMAs each (terms smallest first, as gemm_split.hip), ONE accumulation chain: a dependent
+      // v_mfma_f32_32x32x16_bf16 issues back to back, so a second accumulator would only cost its zeroing and the final add
+#pragma unroll
+      for (int e = 0; e < 16; e++) s[e] = 0.f;
       const unsigned char *kb = reinterpret_cast<const unsigned char *>(sK) + lq * AT_K3_ROWB + lh * 16;
 #pragma unroll
       for (int c = 0; c < 4; c++) {
         const at_bf16x8 k1 = *reinterpret_cast<const at_bf16x8 *>(kb + c * 32);
         const at_bf16x8 k2 = *reinterpret_cast<const at_bf16x8 *>(kb + AT_KT * AT_K3_ROWB + c * 32);
         const at_bf16x8 k3 = *reinterpret_cast<const at_bf16x8 *>(kb + 2 * AT_KT * AT_K3_ROWB + c * 32);
-        f32x16 &t = (c & 1) ? sb : s;
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k3, q3[c][0], t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q3[c][2], t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, q3[c][1], t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, q3[c][0], t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q3[c][1], t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q3[c][0], t, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k3, q3[c][0], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q3[c][2], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, q3[c][1], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, q3[c][0], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q3[c][1], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q3[c][0], s, 0, 0, 0);
       }
+      return;
     } else {
+    f32x16 sb;
+#pragma unroll
+    for (int e = 0; e < 16; e++) s[e] = 0.f, sb[e] = 0.f;
 #pragma unroll
       for (int c = 0; c < 4; c++) {   // two independent accumulation chains (dims 0-31 | 32-63), interleaved
         const f32x4 ka = *reinterpret_cast<const f32x4 *>(&sK[lq * AT_LDK + (2 * c + lh) * 4]);
@@ -379,9 +390,9 @@ __global__ __launch_bounds__(256, (NBUF * UP >= 4 || (S3 && UP > 1)) ? 2 : 3) vo
           sb = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[t], qf[(c + 4) * 4 + t], sb, 0, 0, 0);
         }
       }
-    }
 #pragma unroll
     for (int e = 0; e < 16; e++) s[e] += sb[e];
+    }
   };
   auto softmax_pv = [&](const float *sV, f32x16 &s, int key0) {
     // lane holds keys key0 + (e&3) + 8*(e>>2) + 4*lh  for its query
@@ -391,7 +402,7 @@ __global__ __launch_bounds__(256, (NBUF * UP >= 4 || (S3 && UP > 1)) ? 2 : 3) vo
         const int kb = min(key0 + 8 * g4 + 4 * lh, a.L - 4);  // L % 4 == 0 with a bias; clamped reads are masked below
         const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias_base + kb);
 #pragma unroll
-        for (int t = 0; t < 4; t++) s[g4 * 4 + t] += b4[t];
+        for (int t = 0; t < 4; t++) s[g4 * 4 + t] = S3 ? fmaf(b4[t], AT_LOG2E, s[g4 * 4 + t]) : s[g4 * 4 + t] + b4[t];
       }
     }
     if (key0 + AT_KT > a.L) {
@@ -405,6 +416,26 @@ __global__ __launch_bounds__(256, (NBUF * UP >= 4 || (S3 && UP > 1)) ? 2 : 3) vo
 #pragma unroll
     for (int e = 1; e < 16; e++) mx = fmaxf(mx, s[e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if constexpr (S3) {
+      // log2-domain online softmax with a DEFERRED running maximum (AT_DEFER): most tiles skip the rescale of O and l entirely
+      float psum = 0.f;
+      if (__any(mx > m_run + AT_DEFER || (m_run == -INFINITY && mx != -INFINITY))) {   // wave-uniform
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // whole row masked so far
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);   // m_run = -inf -> 0
+        l_run *= alpha;
+        m_run = m_new;
+#pragma unroll
+        for (int e = 0; e < 16; e++) o0[e] *= alpha, o1[e] *= alpha;
+      }
+      const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        s[e] = __builtin_amdgcn_exp2f(s[e] - m_use);
+        psum += s[e];
+      }
+      l_run += psum;
+    } else {
     const float m_new = fmaxf(m_run, mx);
     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // whole row masked so far
     const float alpha = __expf(m_run - m_use);               // m_run = -inf -> 0 (v_exp_f32 path: ~3e-6 rel. at |x| = 50)
@@ -418,6 +449,7 @@ __global__ __launch_bounds__(256, (NBUF * UP >= 4 || (S3 && UP > 1)) ? 2 : 3) vo
     m_run = m_new;
 #pragma unroll
     for (int e = 0; e < 16; e++) o0[e] *= alpha, o1[e] *= alpha;
+    }
     // ---- O^T[d][q] += sum_key V[key][d] * P[q][key];  k-step e pairs key (e&3)+8*(e>>2)+4*lh ----
     if constexpr (S3) {
       // P (this lane's 16 values, in [0, 1]) -> three bf16 pieces; elements 8 G .. 8 G + 7 are k-slots (lh, 0..7) of group G
@@ -540,18 +572,18 @@ __global__ __launch_bounds__(256, (NBUF * UP >= 4 || (S3 && UP > 1)) ? 2 : 3) vo
         if constexpr (S3) {   // the fp32 q is not kept in registers: one more (L2-hot) read for the single tail key
           const f32x4 q4 = *reinterpret_cast<const f32x4 *>(a.q + q_row * a.ldq + hc + (2 * c + lh) * 4);
 #pragma unroll
-          for (int t = 0; t < 4; t++) sc = fmaf(k4[t], q4[t] * a.scale, sc);
+          for (int t = 0; t < 4; t++) sc = fmaf(k4[t], q4[t] * (a.scale * AT_LOG2E), sc);   // log2 domain, as the MFMA tiles
         } else {
 #pragma unroll
           for (int t = 0; t < 4; t++) sc = fmaf(k4[t], qf[c * 4 + t], sc);
         }
       }
       sc += __shfl_xor(sc, 32);
-      if (bias_base) sc += bias_base[key];
+      if (bias_base) sc += S3 ? bias_base[key] * AT_LOG2E : bias_base[key];
       const float m_new = fmaxf(m_run, sc);
       const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = __expf(m_run - m_use);
-      const float pk = __expf(sc - m_use);
+      const float alpha = S3 ? __builtin_amdgcn_exp2f(m_run - m_use) : __expf(m_run - m_use);
+      const float pk = S3 ? __builtin_amdgcn_exp2f(sc - m_use) : __expf(sc - m_use);
       l_run = l_run * alpha + (lh == 0 ? pk : 0.f);  // l_run is a per-half partial sum: count the key once
       m_run = m_new;
 #pragma unroll

@@ -32,6 +32,7 @@ def profile_begin(max_launches=8192):
     finalize_autotune()
     check(lib.sgic_profiler_begin(_profiler(), int(max_launches)), "sgic_profiler_begin")
     PROFILE = []
+    del PROFILE_TILES[:]
 
 
 def profile_end():
@@ -310,8 +311,14 @@ def _pick_and_launch(key, launch, big_enough, restore=None, modes=None):
         elif key in _CTX and PROFILE is None:
             _ctx_launch(key, launch)
             return True
+    global LAST_TILE
+    LAST_TILE = tile
     launch(tile)
     return False
+
+
+LAST_TILE = 0          # launch mode of the most recent _pick_and_launch (0 = the library's heuristic)
+PROFILE_TILES = []     # launch mode actually used by each record of the current / last profile window (tools/pmc_by_shape.py)
 
 
 # ---- GEMM arithmetic: "f32" = the exact-fp32 MFMA (csrc/gemm.hip), "split3" = fp32-accurate bf16x3 split on the bf16 matrix
@@ -474,6 +481,7 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(
                 return out_planes if out_planes is not None else out
         if PROFILE is not None:
             PROFILE.append((2.0 * M * N * K, (M, N, K, residual is not None, act, "s3")))
+            PROFILE_TILES.append(tile if tile is not None else LAST_TILE)
         return out_planes if out_planes is not None else out
 
     def launch(mode, prof=None):
@@ -488,6 +496,7 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(
             return out
     if PROFILE is not None:   # the launch took the next event pair of the open profile window (profile_begin)
         PROFILE.append((2.0 * M * N * K, (M, N, K, residual is not None, act)))
+        PROFILE_TILES.append(tile if tile is not None else LAST_TILE)
     return out
 
 
@@ -715,6 +724,7 @@ def gemm_batched(a, lda, sa, w, ldw, sw, out, ldc, sc, M, N, K, batch, bias=None
          _cl(sc), M, N, K, act, batch, _opts())
     if PROFILE is not None:
         PROFILE.append((2.0 * M * N * K * batch, ("batched", batch, M, N, K, residual is not None, act)))
+        PROFILE_TILES.append(0)
     return out
 
 
@@ -783,6 +793,7 @@ def conv3x3(x_halo, w, bias, B, H, W, Cin, Cout, residual=None, act=ACT_NONE, ou
                 return out
         if PROFILE is not None:
             PROFILE.append((2.0 * B * H * W * Cout * 9 * Cin, (B * H * W, Cout, 9 * Cin, residual is not None, act, "s3", "conv")))
+            PROFILE_TILES.append(tile if tile is not None else LAST_TILE)
         return out
 
     def launch(mode, prof=None):
@@ -798,6 +809,7 @@ def conv3x3(x_halo, w, bias, B, H, W, Cin, Cout, residual=None, act=ACT_NONE, ou
             return out
     if PROFILE is not None:   # the implicit-GEMM convolution is the same kernel: M = B*H*W, N = Cout, K = 9*Cin
         PROFILE.append((2.0 * B * H * W * Cout * 9 * Cin, (B * H * W, Cout, 9 * Cin, residual is not None, act, "f32", "conv")))
+        PROFILE_TILES.append(tile if tile is not None else LAST_TILE)
     return out
 
 

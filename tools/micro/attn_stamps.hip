@@ -38,7 +38,7 @@ int main() {
       hipMalloc(&bias, (size_t)sh.L * sh.L * 4);
       hipMemset(bias, 0, (size_t)sh.L * sh.L * 4);
     }
-    for (int mode = 1; mode <= 6; mode++) {
+    for (int mode : {1, 5, 9, 10, 13}) {   // 9 / 10 / 13 = 1 / 2 / 5 with both products as bf16x3 split MFMAs (the default arithmetic)
       sgic_launch_opts o{0, mode, nullptr};
       for (int rep = 0; rep < 3; rep++)
         sgic_attention_f32(qkv, 3 * D, qkv + D, 3 * D, qkv + 2 * D, 3 * D, out, D, sh.L, sh.nseq, sh.heads, nullptr, bias, nullptr,
@@ -84,10 +84,10 @@ int main() {
       std::sort(start.begin(), start.end());
       std::sort(endt.begin(), endt.end());
       printf("L=%d mode %d: %.1f us by events; first wave start -> last wave end %.1f us; waves %zu; start p10 %.1f p50 %.1f p90 %.1f max %.1f us | "
-             "end p10 %.1f p50 %.1f p90 %.1f max %.1f us | cycles: prologue p50 %.0f | loop p10 %.0f p50 %.0f p90 %.0f max %.0f | epilogue p50 %.0f\n",
+             "end p10 %.1f p50 %.1f p90 %.1f max %.1f us | cycles: prologue p50 %.0f | loop p10 %.0f p50 %.0f p90 %.0f max %.0f (p50 per 32-key tile %.0f; MFMA floor per tile and wave %d) | epilogue p50 %.0f\n",
              sh.L, mode, ms * 1e3, (tmax - tmin) / 100.0, nw, start[nw / 10], start[nw / 2], start[nw * 9 / 10], start[nw - 1],
              endt[nw / 10], endt[nw / 2], endt[nw * 9 / 10], endt[nw - 1], med(pro), (std::sort(loop.begin(), loop.end()), loop[nw / 10]), loop[nw / 2],
-             loop[nw * 9 / 10], loop[nw - 1], med(epi));
+             loop[nw * 9 / 10], loop[nw - 1], loop[nw / 2] / (sh.L / 32), mode >= 8 ? 1536 : 4096, med(epi));
     }
     hipFree(qkv);
     hipFree(out);

@@ -1,13 +1,15 @@
 """Join the rocprofv3 --pmc passes of `bench.py --steps 1 --warmup 0 --no-secondary --no-cpu-baseline` with the
 launch-ordered GEMM shape list bench.py writes (SGIC_BENCH_SHAPES) -> per-shape HBM-side counter bytes per launch
 (FETCH_SIZE x2-corrected per MI355X_MICROARCH.md + WRITE_SIZE), next to the algorithmic bytes, plus the whole-step summary.
-usage: python tools/pmc_by_shape.py gpurun_out/pmcC gpurun_out/shapes.json profiles/round2_pmc_gemm_by_shape.json profiles/round2_pmc_gemm_summary.json"""
+usage: python tools/pmc_by_shape.py gpurun_out/pmcC gpurun_out/shapes.json profiles/round3_pmc_gemm_by_shape.json profiles/round3_pmc_gemm_summary.json"""
 import csv
 import glob
 import json
+import os
 import sys
 
 root, shapes_json, out_shape, out_sum = sys.argv[1:5]
+STEP_FIRST_KERNEL = sys.argv[5] if len(sys.argv) > 5 else "im2col_patch"   # first kernel of a timed step (decompress: pass its first kernel)
 shapes = json.load(open(shapes_json))
 n = len(shapes)
 
@@ -29,22 +31,52 @@ def dispatches(rec):
     return 2 if (m_full > 0 and m_full * 128 < M) else 1
 
 
-ndisp = [dispatches(r) for r in shapes]
-total_disp = sum(ndisp)
+GEMM_KERNELS = ("gemm_f32_kernel", "gemm_lat16_kernel", "conv3x3_thin", "gemm_split3_")
 s3_share = sum(1 for r in shapes if is_s3(r[0])) / max(1, n)
 
 
+def tail_signature(rec):
+    """(kernel name fragment, grid size in threads) of the SECOND launch of a split-launch record, or None.  The second launch covers the
+    rows beyond the whole rounds with 32x32 tiles (modes 8 / 9 / 12 / 13: 4 waves) or 64x128 tiles (6 / 7: 8 waves)"""
+    key, mode = rec[0], (rec[3] if len(rec) > 3 else None)
+    if not is_s3(key) or mode not in (6, 7, 8, 9, 12, 13) or (len(key) > 6 and key[6] == "conv"):
+        return None
+    M, N = key[0], key[1]
+    tn = 256 if mode in (6, 8, 12) else 128
+    tiles_n, tiles_m = (N + tn - 1) // tn, (M + 127) // 128
+    m_full = (tiles_m * tiles_n // 256) * 256 // tiles_n
+    if not (m_full > 0 and m_full * 128 < M):
+        return None
+    rows = M - m_full * 128
+    if mode in (6, 7):
+        return "gemm_split3_kernel<2, 4, 2, 2,", ((rows + 63) // 64) * ((N + 127) // 128) * 512
+    return "gemm_split3_kernel<2, 2, 1, 1,", ((rows + 31) // 32) * ((N + 31) // 32) * 256
+
+
 def load(tag, counter):
+    """counter value per profile record.  The timed step is located in the dispatch stream by its first kernel (the encoder's
+    im2col_patch: a step launches it twice, encoder then CLIP tower), and every record takes one GEMM-class dispatch plus -- for a
+    split-launch mode -- the following dispatch when its kernel AND grid are the expected tail launch (round 3: counting dispatches
+    from the mode alone drifted by a few launches per step)."""
     rows = []
-    for f in glob.glob(f"{root}_{tag}/**/*counter_collection.csv", recursive=True):
-        rows += [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and
-                 any(k in r["Kernel_Name"] for k in ("gemm_f32_kernel", "gemm_lat16_kernel", "conv3x3_thin", "gemm_split3_kernel"))]
+    for f in sorted(glob.glob(f"{root}_{tag}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)[-1:]:   # the latest run only
+        rows += [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    vals = [float(r["Counter_Value"]) for r in rows[-total_disp:]]
-    out, i = [], 0
-    for d in ndisp:          # a record that is two launches: the counters of both
-        out.append(sum(vals[i:i + d]))
-        i += d
+    starts = [i for i, r in enumerate(rows) if STEP_FIRST_KERNEL in r["Kernel_Name"]]
+    start = starts[-2] if STEP_FIRST_KERNEL == "im2col_patch" and len(starts) >= 2 else (starts[-1] if starts else 0)
+    g = [r for r in rows[start:] if any(k in r["Kernel_Name"] for k in GEMM_KERNELS)]
+    out, p = [], 0
+    for rec in shapes:
+        assert p < len(g), (tag, "ran out of dispatches at record", len(out))
+        v = float(g[p]["Counter_Value"])
+        p += 1
+        sig = tail_signature(rec)
+        if sig is not None and p < len(g) and sig[0] in g[p]["Kernel_Name"] and int(g[p]["Grid_Size"]) == sig[1]:
+            v += float(g[p]["Counter_Value"])
+            p += 1
+        out.append(v)
+    if p != len(g):
+        print(f"[pmc_by_shape] {tag}: {len(g) - p} GEMM-class dispatches of the step left unassigned (of {len(g)})", file=sys.stderr)
     return out
 
 
