@@ -140,8 +140,8 @@ class ShardLoader:
                                              alloc=lambda nbytes: self._buffer(slot, nbytes))   # the slot's pinned buffer: one async H2D copy
                         if (b.jpeg.H, b.jpeg.W) != (h, w):
                             b.jpeg = None
-                    except J.Unsupported:
-                        b.jpeg = None          # progressive / CMYK / ...: this batch takes the host decoder
+                    except Exception:      # noqa: BLE001 -- J.Unsupported (progressive / CMYK / ...) or a file the parser chokes on:
+                        b.jpeg = None      # this batch takes the host decoder, which raises a proper error for a really broken file
                 if b.jpeg is not None:
                     b.u8, b._slot, b._owner = None, slot, self     # the slot returns with release(), after the copy has completed
                     self.gpu_batches += 1

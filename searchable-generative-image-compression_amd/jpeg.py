@@ -189,6 +189,7 @@ def parse(data):
     rst = ff[(nxt >= 0xD0) & (nxt <= 0xD7)]
     keep[rst] = False
     keep[rst + 1] = False
+    keep[ff[nxt == 0xFF]] = False                   # fill bytes (an 0xFF in front of another 0xFF) are not data (T.81 B.1.1.2)
     newpos = np.cumsum(keep) - keep                 # position of every original byte in the cleaned stream
     p.scan = raw[keep]
     p.segs = np.concatenate([[0], newpos[rst]]).astype(np.int32) if len(rst) else np.zeros(1, dtype=np.int32)

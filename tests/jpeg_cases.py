@@ -31,4 +31,10 @@ def cases(small=True):
     buf = io.BytesIO()
     Image.fromarray(natural_like(45, 61, rng, grey=True)).save(buf, "JPEG", quality=70)
     out.append(("grey_45x61", buf.getvalue()))
+    # optional 0xFF fill bytes in front of a marker inside the entropy-coded segment (T.81 B.1.1.2): legal, rare, must be skipped
+    buf = io.BytesIO()
+    Image.fromarray(natural_like(48, 48, rng)).save(buf, "JPEG", quality=85, restart_marker_blocks=2)
+    d = buf.getvalue()
+    i = d.find(b"\xff\xd0", d.find(b"\xff\xda"))
+    out.append(("fill_bytes_before_rst", d[:i] + b"\xff\xff" + d[i:]))
     return out
