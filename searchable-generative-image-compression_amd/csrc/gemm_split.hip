@@ -777,6 +777,139 @@ void gemm_split3_dma_kernel(S3Args g) {
   }
 }
 
+// ---- Ring kernel: the small tiles of launches that cannot fill the chip (single-image requests: M = 289, 545, 256 ...).  Such a
+// launch is one workgroup per CU with one wave per SIMD, so nothing hides what a wave waits for; in the register-staged kernel above a
+// 64-k stage of the 32x32 tile takes ~1000 cycles against ~260 of dependent MFMAs (tools/micro/launch_latency.hip): the LDS write ->
+// barrier -> fragment read -> MFMA sequence of a stage is exposed end to end, and so is most of a load.  Here
+//  * K steps (KS slices of 32 k) are requested by LDS-DMA into a RING of steps, RING - 1 steps ahead of the one being multiplied
+//    (a per-wave `s_waitcnt vmcnt(n)` with n = the DMA instructions of the younger steps: the oldest step has landed, the others fly);
+//  * the fragments of step s + 1 are read from LDS (into the second register set) BEFORE the MFMAs of step s are issued, so per step a
+//    wave pays max(MFMA chain, LDS latency) instead of their sum, with ONE barrier;
+//  * the MFMAs of a step are issued term-major over the wave's blocks (independent accumulators back to back).
+// Per accumulator the sequence is the one of the kernels above (k ascending, six terms smallest first): bitwise identical results.
+// Pieces, swizzle and fragment addressing as in the LDS-DMA kernel.  No convolution mode, K % (32 KS) == 0 (the dispatcher checks).
+template <int WAVES_M, int WAVES_N, int BM, int BN, int KS, int RING>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1)
+void gemm_split3_ring_kernel(S3Args g) {
+  constexpr int NW = WAVES_M * WAVES_N, TM = 16 * BM * WAVES_M, TN = 16 * BN * WAVES_N;
+  constexpr int ROWB = 64, PA = TM / 16, PW = TN / 16, PP = PA + PW, NP = 3 * PP * KS;   // 1 KiB pieces of a step
+  // every wave requests the same number C of pieces per step (its vmcnt arithmetic); when NW does not divide NP the last few requests
+  // wrap around to pieces 0 .. : the same bytes to the same LDS address twice, harmless
+  constexpr int C = (NP + NW - 1) / NW;
+  constexpr int APLANE = TM * ROWB, WPLANE = TN * ROWB, SLICE = 3 * (APLANE + WPLANE), STEP = KS * SLICE;
+  static_assert(RING >= 3 && (RING - 2) * C <= 63, "vmcnt is a 6-bit counter");
+  static_assert(NW * 16 * BM * (16 * BN + 4) * 4 <= RING * STEP, "the epilogue's per-wave slices fit the ring");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN, nwg = tiles_m * tiles_n;
+  int m0, n0;
+  {   // XCD-aware bijective remap + grouped walk, as the kernels above
+    int t = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = t & 7, within = t >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    const int per_group = 8 * tiles_n, group = t / per_group, first_m = group * 8, gsz = min(tiles_m - first_m, 8),
+              in_group = t - group * per_group;
+    m0 = (first_m + in_group % gsz) * TM;
+    n0 = (in_group / gsz) * TN;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = (wave / WAVES_N) * (16 * BM), wn = (wave % WAVES_N) * (16 * BN);
+  auto swz = [](int row) __attribute__((always_inline)) {
+    const int gq = (row >> 2) & 3;
+    return (((gq ^ (gq >> 1)) & 1) << 1) | (gq >> 1);
+  };
+  // this wave's pieces of a step: flat piece f = wave + NW i -> (slice, plane, A piece r | W piece r - PA); lane l fetches row l >> 2,
+  // logical slot (l & 3) ^ swz(row) of the piece into LDS byte 16 l
+  const int prow = lane >> 2, pslot = (lane & 3) ^ swz(prow);
+  const char *src[C];
+  unsigned dst[C];
+#pragma unroll
+  for (int i = 0; i < C; i++) {
+    const int f = (wave + NW * i) % NP, ks = f / (3 * PP), rem = f - ks * (3 * PP), p = rem / PP, r = rem - p * PP;
+    const bool isA = r < PA;
+    const int rw = isA ? min(m0 + r * 16 + prow, g.M - 1) : min(n0 + (r - PA) * 16 + prow, g.N - 1);
+    const unsigned short *base = isA ? g.A + p * g.a_plane : g.W + p * g.w_plane;
+    src[i] = reinterpret_cast<const char *>(base + (size_t)rw * g.K + ks * 32) + pslot * 16;
+    dst[i] = (unsigned)(ks * SLICE + (isA ? p * APLANE + r * 1024 : 3 * APLANE + p * WPLANE + (r - PA) * 1024));
+  }
+  auto dma = [&](int step, int slot) __attribute__((always_inline)) {
+    unsigned char *sbase = smem + slot * STEP;
+    const size_t koff = (size_t)step * (64 * KS);
+#pragma unroll
+    for (int i = 0; i < C; i++)
+      __builtin_amdgcn_global_load_lds((s3_glb_void *)(src[i] + koff), (s3_lds_void *)(sbase + dst[i]), 16, 0, 0);
+  };
+  f32x4 acc[BM][BN];
+#pragma unroll
+  for (int i = 0; i < BM; i++)
+#pragma unroll
+    for (int j = 0; j < BN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int l16 = lane & 15, lq = lane >> 4;
+  const int foff = l16 * ROWB + ((lq ^ swz(l16)) * 16);
+  const int abase = wm * ROWB + foff, bbase = 3 * APLANE + wn * ROWB + foff;
+  bf16x8 af[2][KS][BM][3], wf[2][KS][BN][3];
+  auto read_frags = [&](int slot, auto set_c) __attribute__((always_inline)) {
+    constexpr int S = decltype(set_c)::value;
+    const unsigned char *sbase = smem + slot * STEP;
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+#pragma unroll
+      for (int p = 0; p < 3; p++) {
+#pragma unroll
+        for (int i = 0; i < BM; i++) af[S][ks][i][p] = *reinterpret_cast<const bf16x8 *>(sbase + ks * SLICE + p * APLANE + i * 16 * ROWB + abase);
+#pragma unroll
+        for (int j = 0; j < BN; j++) wf[S][ks][j][p] = *reinterpret_cast<const bf16x8 *>(sbase + ks * SLICE + p * WPLANE + j * 16 * ROWB + bbase);
+      }
+    }
+  };
+  auto compute = [&](auto set_c) __attribute__((always_inline)) {
+    constexpr int S = decltype(set_c)::value;
+    constexpr int TW[6] = {0, 2, 1, 0, 1, 0}, TA[6] = {2, 0, 1, 1, 0, 0};   // (w plane, a plane) of the six terms: a3w1 a1w3 a2w2 a2w1 a1w2 a1w1
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+      for (int t = 0; t < 6; t++)
+#pragma unroll
+        for (int i = 0; i < BM; i++)
+#pragma unroll
+          for (int j = 0; j < BN; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[S][ks][j][TW[t]], af[S][ks][i][TA[t]], acc[i][j], 0, 0, 0);
+  };
+  const int nsteps = g.K / (32 * KS);
+  // prologue: steps 0 .. RING-2 requested, step 0 awaited, its fragments read
+  {
+    const int npro = min(RING - 1, nsteps);
+    for (int s = 0; s < npro; s++) dma(s, s);
+    if (npro == RING - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * C) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, IntC<0>{});
+  }
+  int slot_next = 1 % RING;          // slot of step s + 1
+  int slot_fill = (RING - 1) % RING; // slot step s + RING - 1 goes to (= the slot of step s - 1)
+  auto iter = [&](int s, auto set_c) __attribute__((always_inline)) {
+    constexpr int S = decltype(set_c)::value;
+    if (s + 1 < nsteps) {
+      // step s + 1 has landed: RING - 3 younger steps may still fly (fewer were requested near the end: wait for everything there)
+      if (s + RING - 2 <= nsteps - 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((RING - 3) * C) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // ... for every wave's pieces; and every wave is past its reads of step s - 1 (and s)
+      if (s + RING - 1 < nsteps) dma(s + RING - 1, slot_fill);
+      read_frags(slot_next, IntC<S ^ 1>{});
+      slot_next = slot_next + 1 == RING ? 0 : slot_next + 1;
+      slot_fill = slot_fill + 1 == RING ? 0 : slot_fill + 1;
+    }
+    compute(set_c);
+  };
+  for (int s = 0; s < nsteps; s += 2) {
+    iter(s, IntC<0>{});
+    if (s + 1 < nsteps) iter(s + 1, IntC<1>{});
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();   // every wave's fragment reads are done: the ring becomes the epilogue's scratch
+  s3_tile_epilogue<BM, BN, 1>(g, acc, reinterpret_cast<float *>(smem) + wave * (16 * BM * (16 * BN + 4)), m0, n0, wm, wn, lane);
+}
+
 // x = x1 + x2 + x3: planes [3][rows][cols] (bf16 bit patterns).  cols % 8 == 0, 16-byte aligned rows.
 extern "C" int sgic_split3_f32(const float *d_x, int ld, int rows, int cols, int seg, int seg_stride, uint16_t *d_planes,
                                sgic_stream_t stream) {
@@ -790,7 +923,7 @@ extern "C" int sgic_split3_f32(const float *d_x, int ld, int rows, int cols, int
   return sgic::check_launch("split3_rows_kernel");
 }
 
-#define SGIC_SPLIT3_TILE_MODES 17
+#define SGIC_SPLIT3_TILE_MODES 25
 
 template <int WAVES_M, int WAVES_N, int BM, int BN, int NS, int KS = 1, bool PERSIST = false>
 static int s3_launch(const S3Args &g, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
@@ -838,6 +971,28 @@ static int s3_launch_dma(const S3Args &g, hipStream_t st, hipEvent_t ev_start, h
   return sgic::check_launch("gemm_split3_dma_kernel");
 }
 
+template <int WAVES_M, int WAVES_N, int BM, int BN, int KS, int RING>
+static int s3_launch_ring(const S3Args &g, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  constexpr int NT = 64 * WAVES_M * WAVES_N, TM = 16 * BM * WAVES_M, TN = 16 * BN * WAVES_N;
+  constexpr int LDS = RING * KS * 3 * (TM + TN) * 64;
+  static_assert(LDS <= 160 * 1024, "LDS of a CU");
+  static bool attr_set[64] = {};   // per device, as s3_launch
+  auto kernel = gemm_split3_ring_kernel<WAVES_M, WAVES_N, BM, BN, KS, RING>;
+  int dev = 0;
+  SGIC_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    SGIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
+  const dim3 grid((unsigned)(((g.M + TM - 1) / TM) * ((g.N + TN - 1) / TN)));
+  if (ev_start || ev_stop) {
+    hipExtLaunchKernelGGL(kernel, grid, dim3(NT), LDS, st, ev_start, ev_stop, 0, g);
+  } else {
+    kernel<<<grid, NT, LDS, st>>>(g);
+  }
+  return sgic::check_launch("gemm_split3_ring_kernel");
+}
+
 // Which kernel a tile mode runs (round 3, tools/micro/split3_phases.hip on the model's shapes): the 128x256 / 256x128 tiles take the
 // LDS-DMA kernel (a slice is ~3000 cycles: the DMA latency hides; 3-9 % shorter launches than register staging), the 128x128 tile
 // keeps register staging under its old numbers (its slices are half as long and long-K shapes lose ~10 % with one slice of cover)
@@ -854,6 +1009,19 @@ static int s3_mode(const S3Args &g, int mode, hipStream_t st, hipEvent_t e0, hip
     case 16: return dma_ok ? s3_launch_dma<2, 4, 4, 2>(g, st, e0, e1) : s3_launch<2, 4, 4, 2, 1>(g, st, e0, e1);
     case 17: return dma_ok ? s3_launch_dma<2, 4, 4, 2, true>(g, st, e0, e1) : s3_launch<2, 4, 4, 2, 1, 1, true>(g, st, e0, e1);
     case 2: return s3_launch<2, 4, 4, 2, 1>(g, st, e0, e1);
+    // 18-22: the ring kernel (small tiles, deep LDS-DMA prefetch) for launches that cannot fill the chip; shapes it does not take
+    // (a convolution, K not a multiple of its step) run the register-staged tile of the same size
+    case 18: return (!g.conv_C && g.K % 64 == 0) ? s3_launch_ring<2, 2, 1, 1, 2, 6>(g, st, e0, e1) : s3_mode(g, 4, st, e0, e1);   // 32x32
+    case 19: return (!g.conv_C && g.K % 64 == 0) ? s3_launch_ring<2, 2, 2, 1, 2, 4>(g, st, e0, e1) : s3_mode(g, 4, st, e0, e1);   // 64x32
+    case 20: return (!g.conv_C && g.K % 64 == 0) ? s3_launch_ring<2, 2, 1, 2, 2, 4>(g, st, e0, e1) : s3_mode(g, 4, st, e0, e1);   // 32x64
+    case 21: return !g.conv_C ? s3_launch_ring<2, 2, 2, 2, 1, 6>(g, st, e0, e1) : s3_mode(g, 3, st, e0, e1);                       // 64x64, four waves
+    case 22: return !g.conv_C ? s3_launch_ring<2, 4, 2, 1, 1, 6>(g, st, e0, e1) : s3_mode(g, 3, st, e0, e1);                       // 64x64, eight waves
+    // 23-25: tiles cut for ONE image's token count (M = 289 -> 19 row blocks: four tiles of 80 rows, or ten of 32) so that N / TN column
+    // tiles x those make <= 256 workgroups, one per CU: a launch of this size is bound by what ONE CU can pull from L2 (~55 GB/s measured,
+    // whatever the depth of the ring), i.e. by (TM + TN) K bytes per workgroup with every CU busy
+    case 23: return !g.conv_C ? s3_launch_ring<1, 4, 5, 1, 1, 5>(g, st, e0, e1) : s3_mode(g, 3, st, e0, e1);                       // 80x64
+    case 24: return !g.conv_C ? s3_launch_ring<1, 3, 5, 1, 1, 6>(g, st, e0, e1) : s3_mode(g, 3, st, e0, e1);                       // 80x48
+    case 25: return (!g.conv_C && g.K % 64 == 0) ? s3_launch_ring<2, 3, 1, 1, 2, 5>(g, st, e0, e1) : s3_mode(g, 4, st, e0, e1);   // 32x48
     case 11: return s3_launch<2, 4, 4, 2, 1, 1, true>(g, st, e0, e1);
     // the 32x32 latency tile: 64-k stages when K allows (and, for a convolution, a stage stays inside one tap)
     case 3: return s3_launch<2, 2, 2, 2, 4>(g, st, e0, e1);   // (64-k stages measured no better for the 64x64 tile)

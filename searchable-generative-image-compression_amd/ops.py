@@ -102,7 +102,7 @@ def _remember(key, mode, dirty=True):
     _DIRTY = _DIRTY or dirty
 
 
-_MAX_MODE = {"gemm": 15, "conv3x3": 15, "gemm3": 17, "conv3": 17, "attn": 6, "attn3": 6}   # per kind of key
+_MAX_MODE = {"gemm": 15, "conv3x3": 15, "gemm3": 25, "conv3": 25, "attn": 6, "attn3": 6}   # per kind of key
 
 
 def _load_tile_cache():
@@ -326,7 +326,14 @@ PROFILE_TILES = []     # launch mode actually used by each record of the current
 # depend on (N, K) and on the operands' kinds, never on M, so single-image and batched requests stay bitwise identical.
 PRECISION = os.environ.get("SGIC_GEMM", "split3")
 assert PRECISION in ("f32", "split3"), f"SGIC_GEMM={PRECISION!r}: expected f32 or split3"
-SPLIT3_MODES = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17)
+SPLIT3_MODES = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25)
+SPLIT3_RING_MODES = (18, 19, 20, 21, 22, 23, 24, 25)   # small tiles, deep LDS-DMA ring: raced only for launches that cannot fill the chip (_split3_modes)
+SPLIT3_SMALL_M = 2048
+
+
+def _split3_modes(M):
+    """candidate launch modes of a split GEMM with M rows: the ring kernel's 32..64-row tiles are for single-image sized launches"""
+    return SPLIT3_MODES if M <= SPLIT3_SMALL_M else tuple(m for m in SPLIT3_MODES if m not in SPLIT3_RING_MODES)
 _W3 = {}          # (data_ptr, N, K, ldw, version) -> (planes, w): the weight is pinned so its address cannot be reused
 _W3_BYTES = 0
 _W3_LIMIT = 24 << 30
@@ -477,7 +484,7 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(
             launch3(tile)
         else:
             key = ("gemm3", M, N, K, int(residual is not None), act)
-            if _pick_and_launch(key, launch3, M * N >= (1 << 16), restore=out if inplace else None, modes=SPLIT3_MODES):
+            if _pick_and_launch(key, launch3, M * N >= (1 << 16), restore=out if inplace else None, modes=_split3_modes(M)):
                 return out_planes if out_planes is not None else out
         if PROFILE is not None:
             PROFILE.append((2.0 * M * N * K, (M, N, K, residual is not None, act, "s3")))

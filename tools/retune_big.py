@@ -3,6 +3,8 @@
 (after a kernel change: round 3 moved the 128x256 / 256x128 tiles to LDS-DMA staging and added modes 16 / 17).
 Durations are dispatch timestamps (ops.profile_begin / profile_end), median of `reps` launches per mode, two interleaved passes.
 Writes gpurun_out/retune_big.json = {"picks": {key: mode}, "table": {key: {mode: us}}}; merge into the in-tree cache with --merge.
+--small: the split GEMMs of single-image sized launches instead (M <= ops.SPLIT3_SMALL_M: the small register-staged tiles against the
+ring kernel's modes 18-22) -> gpurun_out/retune_small.json.
 (Replaces the round-2 one-off scripts gemm_big_modes.py / conv_modes.py / gemm_shapes_modes.py.)"""
 import json
 import os
@@ -10,7 +12,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-OUT = os.path.join(ROOT, "gpurun_out", "retune_big.json")
+SMALL = "--small" in sys.argv
+OUT = os.path.join(ROOT, "gpurun_out", "retune_small.json" if SMALL else "retune_big.json")
+SMALL_MODES = (3, 4, 5, 18, 19, 20, 21, 22, 23, 24, 25)
 GEMM_MODES = (1, 2, 5, 6, 7, 8, 9, 10, 11, 12, 13, 16, 17)
 CONV_MODES = (1, 2, 3, 5, 10, 11, 14, 15, 16, 17)
 
@@ -54,7 +58,10 @@ def main():
         nums = [int(x) for x in nums]
         if kind == "gemm3":
             M, N, K, res, act = nums
-            if M * N < (1 << 21) or old in (3, 4):
+            if SMALL:
+                if M > ops.SPLIT3_SMALL_M or M * N < (1 << 16):
+                    continue
+            elif M * N < (1 << 21) or old in (3, 4):
                 continue
             a = torch.randn(M, K, device=dev, generator=g)
             w = torch.randn(N, K, device=dev, generator=g) * 0.03
@@ -63,13 +70,13 @@ def main():
             ap = ops.Planes(M, K, dev)
             ops.split3(a, out=ap.t.view(3, M, K))
             out = torch.empty(M, N, device=dev)
-            modes = [m for m in GEMM_MODES if not (m in (1, 6, 8, 10, 12) and N < 256)]
+            modes = list(SMALL_MODES) if SMALL else [m for m in GEMM_MODES if not (m in (1, 6, 8, 10, 12) and N < 256)]
             t = race(lambda m: ops.gemm(ap, w, b, residual=r, act=act, out=out, tile=m, precision="split3"), modes)
             fl = 2.0 * M * N * K
         elif kind == "conv3":
             M, H, W, Cin, Cout, res, act = nums
             B = M // (H * W)
-            if M * Cout < (1 << 21) or old in (3, 4):
+            if SMALL or M * Cout < (1 << 21) or old in (3, 4):
                 continue
             halo = torch.zeros(B, H + 2, W + 2, Cin, device=dev)
             halo[:, 1:-1, 1:-1] = torch.randn(B, H, W, Cin, device=dev, generator=g)
