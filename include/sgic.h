@@ -132,6 +132,7 @@ typedef struct sgic_launch_opts {
   int tile_mode;
   int attn_mode;
   sgic_profiler *profiler;
+  int w_packed;   /* split GEMM / convolution: d_Wplanes is in the slice-major layout of sgic_split3_pack_f32 */
 } sgic_launch_opts;
 
 /* Profile window for the roofline figure of bench.py.  One profiler per launching thread.  begin() opens a window,
@@ -226,6 +227,9 @@ int sgic_l2norm_u8(const float *d_x, int ldx, int M, int D, float *d_unit, uint8
  *   (global_load_lds: no register pass, no ds_write), the other tiles through registers; all modes are bitwise identical. */
 int sgic_split3_f32(const float *d_x, int ld, int rows, int cols, int seg, int seg_stride, uint16_t *d_planes,
                     sgic_stream_t stream);
+/* planes of a constant W operand [rows = N][cols = K] in the slice-major layout [3][K / 32][N][32] (opts->w_packed = 1 at the
+ * consuming call): a 16-row piece of a 32-k slice is 1 KiB of consecutive bytes (whole cache lines) for the LDS-DMA staging.  K % 32 == 0. */
+int sgic_split3_pack_f32(const float *d_x, int ld, int rows, int cols, uint16_t *d_planes, sgic_stream_t stream);
 int sgic_gemm_split3_f32(const float *d_A, int lda, int a_seg, int a_seg_stride, uint16_t *d_Aplanes,
                          const uint16_t *d_Wplanes, const float *d_bias, const float *d_R, int ldr, float *d_C, int ldc,
                          uint16_t *d_Cplanes, int M, int N, int K, int act, int c_seg, int c_seg_stride,

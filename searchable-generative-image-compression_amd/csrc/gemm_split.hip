@@ -36,6 +36,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // x[rows, cols] fp32 (row map as sgic_gemm_f32's A operand) -> planes [3][rows][cols] bf16; 8 elements per thread
+// PACK: the slice-major layout [3][cols / 32][rows][32] instead (a constant W operand: 16 rows of a 32-k slice = 1 KiB contiguous)
+template <bool PACK>
 __global__ __launch_bounds__(256) void split3_rows_kernel(const float *__restrict__ x, int ld, int rows, int cols, int seg,
                                                           int seg_stride, unsigned short *__restrict__ planes) {
   const int c8 = cols >> 3;
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void split3_rows_kernel(const float *__restric
     s3_split_pair(v0[2], v0[3], p1[1], p2[1], p3[1]);
     s3_split_pair(v1[0], v1[1], p1[2], p2[2], p3[2]);
     s3_split_pair(v1[2], v1[3], p1[3], p2[3], p3[3]);
-    const size_t dst = (size_t)r * cols + c;
+    const size_t dst = PACK ? ((size_t)(c >> 5) * rows + r) * 32 + (c & 31) : (size_t)r * cols + c;
     *reinterpret_cast<u32x4 *>(planes + dst) = u32x4{p1[0], p1[1], p1[2], p1[3]};
     *reinterpret_cast<u32x4 *>(planes + plane + dst) = u32x4{p2[0], p2[1], p2[2], p2[3]};
     *reinterpret_cast<u32x4 *>(planes + 2 * plane + dst) = u32x4{p3[0], p3[1], p3[2], p3[3]};
@@ -78,6 +80,7 @@ struct S3Args {
   // row m = output pixel (b,y,x), K = 9 C ordered (ky,kx,c); conv_C == 0 disables.  C % 32 == 0: a K slice never straddles a tap
   int conv_C, conv_H, conv_W;
   int m_base;                    // logical row of this launch's row 0 (second launch of the split modes 6 / 7): enters the C row map
+  int w_packed;                  // W planes are slice-major [3][K / 32][N][32] (sgic_split3_pack_f32) instead of [3][N][K]
 };
 
 // ---- epilogue of one tile, shared by the register-staged and the LDS-DMA kernel: the accumulators hold
@@ -219,7 +222,8 @@ __device__ __forceinline__ void s3_tile_epilogue(const S3Args &g, f32x4 (&acc)[B
 // start and the last workgroup's end, and s_memtime (shader clock) over the same span of workgroup 0 -- what a launch takes
 // on the shader array itself, beside its dispatch timestamps.  No stamp executes in the product build.
 // S3_ABLATE (diagnostic builds of tools/micro/split3_phases.hip only; results are garbage): bit 0 = no global loads in the main
-// loop, bit 1 = no LDS writes, bit 2 = no barrier, bit 3 = no fragment reads -- what each part of the K loop costs beside the MFMAs
+// loop, bit 1 = no LDS writes, bit 2 = no barrier, bit 3 = no fragment reads -- what each part of the K loop costs beside the MFMAs;
+// bits 4 / 5 / 6 (LDS-DMA kernel): operand reads of tile (0,0) / (m,0) only; operands addressed as if stored tile-packed
 #ifndef S3_ABLATE
 #define S3_ABLATE 0
 #endif
@@ -291,7 +295,11 @@ void gemm_split3_kernel(S3Args g) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < CW; i++) wptr[i] = g.W + (size_t)min(n0 + srow + i * (NT / SL), g.N - 1) * g.K + sslot * 8;
+    for (int i = 0; i < CW; i++) {
+      const size_t wr = (size_t)min(n0 + srow + i * (NT / SL), g.N - 1);
+      // packed W: slot sslot of a 64 KS-byte stage row = slice sslot / 4, 16-byte chunk sslot % 4
+      wptr[i] = g.w_packed ? g.W + ((size_t)(sslot >> 2) * g.N + wr) * 32 + (sslot & 3) * 8 : g.W + wr * g.K + sslot * 8;
+    }
   };
   setup();
   const bool a_on = CA * NT == TM * SL || srow < TM, w_on = CW * NT == TN * SL || srow < TN;   // tiles smaller than a pass
@@ -304,12 +312,13 @@ void gemm_split3_kernel(S3Args g) {
       const int tap = k0 / g.conv_C, c0 = k0 - tap * g.conv_C, ky = tap / 3, kx = tap - 3 * ky;
       ka = (ky * (g.conv_W + 2) + kx) * g.conv_C + c0;
     }
+    const size_t kw = g.w_packed ? (size_t)k0 * g.N : (size_t)k0;   // packed: slice k0 / 32 starts (k0 / 32) N 32 elements in
 #pragma unroll
     for (int p = 0; p < 3; p++) {
 #pragma unroll
       for (int i = 0; i < CA; i++) ra[S][p][i] = *reinterpret_cast<const u32x4 *>(aptr[i] + p * g.a_plane + ka);
 #pragma unroll
-      for (int i = 0; i < CW; i++) rw[S][p][i] = *reinterpret_cast<const u32x4 *>(wptr[i] + p * g.w_plane + k0);
+      for (int i = 0; i < CW; i++) rw[S][p][i] = *reinterpret_cast<const u32x4 *>(wptr[i] + p * g.w_plane + kw);
     }
   };
   auto store = [&](int buf, auto set_c) __attribute__((always_inline)) {
@@ -613,17 +622,19 @@ void gemm_split3_dma_kernel(S3Args g) {
   auto setup = [&]() __attribute__((always_inline)) {
     const size_t a0 = g.conv_C ? conv_off(min(m0, g.M - 1)) : (size_t)m0 * g.K;
     baseA = g.A + a0;
-    baseW = g.W + (size_t)n0 * g.K;
+    baseW = g.W + (size_t)n0 * (g.w_packed ? 32 : g.K);
 #pragma unroll
     for (int i = 0; i < CA; i++) {
       const int am = min(m0 + (wave + NW * i) * 16 + prow, g.M - 1);
       const size_t off = g.conv_C ? conv_off(am) : (size_t)am * g.K;
       voffA[i] = (unsigned)((off - a0) * 2 + pslot * 16);
+      if ((S3_ABLATE & 192) == 64) voffA[i] = (unsigned)((wave + NW * i) * 1024 + lane * 16);   // diagnostic: bit 6 = operands read as if stored tile-packed (a piece = 1 KiB contiguous); bits 6+7 = W only
     }
 #pragma unroll
     for (int i = 0; i < CW; i++) {
       const int wr = min(n0 + (wave + NW * i) * 16 + prow, g.N - 1);
-      voffW[i] = (unsigned)(((size_t)(wr - n0) * g.K) * 2 + pslot * 16);
+      voffW[i] = (unsigned)(((size_t)(wr - n0) * (g.w_packed ? 32 : g.K)) * 2 + pslot * 16);
+      if (S3_ABLATE & 64) voffW[i] = (unsigned)((wave + NW * i) * 1024 + lane * 16);
     }
   };
   setup();
@@ -638,8 +649,8 @@ void gemm_split3_dma_kernel(S3Args g) {
     unsigned char *stage = smem + buf * STAGE;
 #pragma unroll
     for (int p = 0; p < 3; p++) {
-      const char *pa = reinterpret_cast<const char *>(baseA + p * g.a_plane + ka);
-      const char *pw = reinterpret_cast<const char *>(baseW + p * g.w_plane + k0);
+      const char *pa = reinterpret_cast<const char *>(baseA + p * g.a_plane + (((S3_ABLATE & 192) == 64) ? (k0 / 32) * (TM * 32) : ka));
+      const char *pw = reinterpret_cast<const char *>(baseW + p * g.w_plane + ((S3_ABLATE & 64) ? (size_t)(k0 / 32) * (TN * 32) : (g.w_packed ? (size_t)k0 * g.N : (size_t)k0)));
 #pragma unroll
       for (int i = 0; i < CA; i++)
         __builtin_amdgcn_global_load_lds((s3_glb_void *)(pa + voffA[i]), (s3_lds_void *)(stage + p * APLANE + (wave + NW * i) * 1024), 16, 0, 0);
@@ -822,6 +833,7 @@ void gemm_split3_ring_kernel(S3Args g) {
   // logical slot (l & 3) ^ swz(row) of the piece into LDS byte 16 l
   const int prow = lane >> 2, pslot = (lane & 3) ^ swz(prow);
   const char *src[C];
+  size_t kmul[C];     // wave-uniform
   unsigned dst[C];
 #pragma unroll
   for (int i = 0; i < C; i++) {
@@ -829,15 +841,16 @@ void gemm_split3_ring_kernel(S3Args g) {
     const bool isA = r < PA;
     const int rw = isA ? min(m0 + r * 16 + prow, g.M - 1) : min(n0 + (r - PA) * 16 + prow, g.N - 1);
     const unsigned short *base = isA ? g.A + p * g.a_plane : g.W + p * g.w_plane;
-    src[i] = reinterpret_cast<const char *>(base + (size_t)rw * g.K + ks * 32) + pslot * 16;
+    const bool packed = !isA && g.w_packed;
+    src[i] = reinterpret_cast<const char *>(base + (packed ? ((size_t)ks * g.N + rw) * 32 : (size_t)rw * g.K + ks * 32)) + pslot * 16;
+    kmul[i] = packed ? (size_t)g.N * (64 * KS) : (size_t)(64 * KS);   // bytes per K step
     dst[i] = (unsigned)(ks * SLICE + (isA ? p * APLANE + r * 1024 : 3 * APLANE + p * WPLANE + (r - PA) * 1024));
   }
   auto dma = [&](int step, int slot) __attribute__((always_inline)) {
     unsigned char *sbase = smem + slot * STEP;
-    const size_t koff = (size_t)step * (64 * KS);
 #pragma unroll
     for (int i = 0; i < C; i++)
-      __builtin_amdgcn_global_load_lds((s3_glb_void *)(src[i] + koff), (s3_lds_void *)(sbase + dst[i]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((s3_glb_void *)(src[i] + (size_t)step * kmul[i]), (s3_lds_void *)(sbase + dst[i]), 16, 0, 0);
   };
   f32x4 acc[BM][BN];
 #pragma unroll
@@ -919,8 +932,22 @@ extern "C" int sgic_split3_f32(const float *d_x, int ld, int rows, int cols, int
   SGIC_REQUIRE(seg >= 0 && (seg == 0 || seg_stride >= seg), "row segment map");
   const long total = (long)rows * (cols >> 3);
   const unsigned grid = (unsigned)min((total + 255) / 256, 256L * 16);
-  split3_rows_kernel<<<grid, 256, 0, to_stream(stream)>>>(d_x, ld, rows, cols, seg, seg_stride, d_planes);
+  split3_rows_kernel<false><<<grid, 256, 0, to_stream(stream)>>>(d_x, ld, rows, cols, seg, seg_stride, d_planes);
   return sgic::check_launch("split3_rows_kernel");
+}
+
+// The planes of a CONSTANT W operand in the slice-major layout [3][cols / 32][rows][32] (opts->w_packed of the GEMM / convolution
+// entry points): the 16 rows x 64 B piece a wave requests per instruction is then 1 KiB of consecutive bytes instead of sixteen
+// half cache lines 2 cols bytes apart.  Measured (tools/micro/cu_l2_bandwidth.hip, split3_phases -DS3_ABLATE=64): a CU pulls 76 GB/s
+// in the strided shape against 105-120 GB/s contiguous with the chip loaded; the 128x256 tile gains 6-13 % with packed operands.
+extern "C" int sgic_split3_pack_f32(const float *d_x, int ld, int rows, int cols, uint16_t *d_planes, sgic_stream_t stream) {
+  SGIC_REQUIRE(d_x && d_planes && rows > 0 && cols > 0, "null/empty");
+  SGIC_REQUIRE((cols & 31) == 0 && (ld & 3) == 0 && ld >= cols, "cols % 32, ld % 4");
+  SGIC_REQUIRE(((uintptr_t)d_x & 15) == 0 && ((uintptr_t)d_planes & 15) == 0, "16-byte alignment");
+  const long total = (long)rows * (cols >> 3);
+  const unsigned grid = (unsigned)min((total + 255) / 256, 256L * 16);
+  split3_rows_kernel<true><<<grid, 256, 0, to_stream(stream)>>>(d_x, ld, rows, cols, 0, 0, d_planes);
+  return sgic::check_launch("split3_rows_kernel<pack>");
 }
 
 #define SGIC_SPLIT3_TILE_MODES 25
@@ -1099,7 +1126,8 @@ extern "C" int sgic_gemm_split3_f32(const float *d_A, int lda, int a_seg, int a_
   const int vec = (N % 4 == 0) && (!d_bias || ((uintptr_t)d_bias & 15) == 0) && (!d_R || ((ldr % 4 == 0) && ((uintptr_t)d_R & 15) == 0)) &&
                   (d_Cplanes ? ((uintptr_t)d_Cplanes & 7) == 0 : ((ldc % 4 == 0) && ((uintptr_t)d_C & 15) == 0));
   SGIC_REQUIRE(!d_Cplanes || (vec && c_seg == 0), "planes output needs float4-addressable operands and no row map");
-  S3Args g{d_Aplanes, d_Wplanes, d_bias, d_R, d_C, M, N, K, ldr, ldc, act, c_seg, c_seg_stride, (long)M * K, (long)N * K, d_Cplanes, (long)M * N, vec, 0, 0, 0, 0};
+  S3Args g{d_Aplanes, d_Wplanes, d_bias, d_R, d_C, M, N, K, ldr, ldc, act, c_seg, c_seg_stride, (long)M * K, (long)N * K, d_Cplanes, (long)M * N, vec, 0, 0, 0, 0,
+           opts ? opts->w_packed : 0};
   return s3_dispatch(g, opts, to_stream(stream));
 }
 
@@ -1118,6 +1146,7 @@ extern "C" int sgic_conv3x3_split3_f32(const uint16_t *d_in_planes, const uint16
   const int M = (int)Ml, N = Cout, K = 9 * Cin;
   const int vec = (N % 4 == 0) && (!d_bias || ((uintptr_t)d_bias & 15) == 0) && (!d_R || ((ldr % 4 == 0) && ((uintptr_t)d_R & 15) == 0)) &&
                   (ldc % 4 == 0) && ((uintptr_t)d_out & 15) == 0;
-  S3Args g{d_in_planes, d_Wplanes, d_bias, d_R, d_out, M, N, K, ldr, ldc, act, 0, 0, halo_rows * Cin, (long)N * K, nullptr, 0, vec, Cin, H, W, 0};
+  S3Args g{d_in_planes, d_Wplanes, d_bias, d_R, d_out, M, N, K, ldr, ldc, act, 0, 0, halo_rows * Cin, (long)N * K, nullptr, 0, vec, Cin, H, W, 0,
+           opts ? opts->w_packed : 0};
   return s3_dispatch(g, opts, to_stream(stream));
 }

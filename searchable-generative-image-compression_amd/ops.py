@@ -49,9 +49,9 @@ def profile_end():
     return [(fl, float(buf[i]), key) for i, (fl, key) in enumerate(recs)]
 
 
-def _opts(tile=0, attn=0, prof=None):
+def _opts(tile=0, attn=0, prof=None, w_packed=0):
     """prof: an explicit profiler handle (the tuner's probes); default: the bench's window when one is open"""
-    return launch_opts(tile, attn, prof if prof is not None else (_PROFILER if PROFILE is not None else None))
+    return launch_opts(tile, attn, prof if prof is not None else (_PROFILER if PROFILE is not None else None), w_packed)
 
 
 def _rows(t):
@@ -391,14 +391,15 @@ def split3(x, ld=None, rows=None, seg=(0, 0), out=None):
 
 
 def weight_planes(w, ldw):
-    """bf16x3 planes of a constant operand, split once (keyed by address + in-place version)"""
+    """bf16x3 planes of a constant operand, split once (keyed by address + in-place version), in the slice-major layout
+    [3][K / 32][N][32] of sgic_split3_pack_f32: consumers pass w_packed=1 (sgic_launch_opts)"""
     global _W3_BYTES
     N, K = w.shape
     key = (w.data_ptr(), N, K, ldw, w._version)
     hit = _W3.get(key)
     if hit is None:
         planes = torch.empty(3, N, K, device=w.device, dtype=torch.int16)
-        call("sgic_split3_f32", _p(w), ldw, N, K, 0, 0, _p(planes))
+        call("sgic_split3_pack_f32", _p(w), ldw, N, K, _p(planes))
         nbytes = planes.numel() * 2
         while _W3 and _W3_BYTES + nbytes > _W3_LIMIT:      # oldest first
             old = next(iter(_W3))
@@ -478,7 +479,7 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(
 
         def launch3(mode, prof=None):
             call("sgic_gemm_split3_f32", _p(a_f32), lda, a_seg[0], a_seg[1], _p(ap), _p(wp), _p(bias), _p(residual), ldr, _p(out), ldc,
-                 _p(cp), M, N, K, act, c_seg[0], c_seg[1], _opts(tile=mode, prof=prof))
+                 _p(cp), M, N, K, act, c_seg[0], c_seg[1], _opts(tile=mode, prof=prof, w_packed=1))
 
         if tile is not None:
             launch3(tile)
@@ -790,7 +791,7 @@ def conv3x3(x_halo, w, bias, B, H, W, Cin, Cout, residual=None, act=ACT_NONE, ou
 
         def launch3(mode, prof=None):
             call("sgic_conv3x3_split3_f32", _p(ws), _p(wp), _p(bias), _p(residual), ldr, _p(out), ldc, B, H, W, Cin, Cout, act,
-                 _opts(tile=mode, prof=prof))
+                 _opts(tile=mode, prof=prof, w_packed=1))
 
         if tile is not None:
             launch3(tile)

@@ -254,3 +254,25 @@ def test_edge_shapes_every_mode(ops, M, N, K):
         assert float((out.double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())), tile
         first = out if first is None else first
         assert torch.equal(out, first), tile
+
+
+def test_row_major_and_slice_major_weight_planes_agree(ops):
+    """W planes in the plain [3][N][K] layout (sgic_split3_f32, opts->w_packed = 0: what a C caller without the packing pass hands
+    over) and in the slice-major layout ops.gemm uses (sgic_split3_pack_f32, w_packed = 1) give bitwise the same product, for a
+    register-staged tile (5), an LDS-DMA tile (1) and the ring kernel (19, 23)"""
+    from sgic_amd._lib import call, launch_opts
+    from sgic_amd.ops import _p
+    g = torch.Generator(device="cuda").manual_seed(5)
+    M, N, K = 600, 520, 448
+    a = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) * 0.1
+    bias = torch.randn(N, device="cuda", generator=g)
+    ref = ops.gemm(a, w, bias, precision="split3", tile=2)
+    ap = ops.split3(a)
+    wp = ops.split3(w)                       # row-major planes
+    for tile in (1, 5, 19, 23, 4):
+        out = torch.empty(M, N, device="cuda")
+        call("sgic_gemm_split3_f32", None, 0, 0, 0, _p(ap), _p(wp), _p(bias), None, 0, _p(out), N, None, M, N, K, 0, 0, 0,
+             launch_opts(tile, 0, None, 0))
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), tile
