@@ -133,6 +133,9 @@ typedef struct sgic_launch_opts {
   int attn_mode;
   sgic_profiler *profiler;
   int w_packed;   /* split GEMM / convolution: d_Wplanes is in the slice-major layout of sgic_split3_pack_f32 */
+  int a_packed;   /* split GEMM with d_A == NULL: d_Aplanes is slice-major [3][K / 32][M][32] -- what sgic_layernorm_split3_f32,
+                     sgic_attention_split3_f32, a GEMM's d_Cplanes output and sgic_split3_pack_f32 write; 0 = row-major [3][M][K]
+                     (sgic_split3_f32) */
 } sgic_launch_opts;
 
 /* Profile window for the roofline figure of bench.py.  One profiler per launching thread.  begin() opens a window,
@@ -217,7 +220,8 @@ int sgic_l2norm_u8(const float *d_x, int ldx, int M, int D, float *d_unit, uint8
  *   cols % 8 == 0.  Weights are split once at load time.
  * sgic_gemm_split3_f32: d_A != NULL: A is split into the caller's workspace d_Aplanes (3*M*K uint16) first;
  *   d_A == NULL: d_Aplanes already holds the planes.  K % 32 == 0.
- *   d_Cplanes != NULL: the result is written as planes [3][M][N] (the next GEMM's A operand) instead of d_C.
+ *   d_Cplanes != NULL: the result is written as slice-major planes [3][N / 32][M][32] (the next GEMM's A operand with
+ *   opts->a_packed = 1) instead of d_C; N % 32 == 0.
  *   opts->tile_mode: 0 = heuristic, 1 = 128x256, 2 = 128x128, 3 = 64x64, 4 = 32x32 (the latency kernel for
  *   under-filled launches), 5 = 64x128 (two workgroups per CU) workgroup tiles, 6 / 7 = 1 / 2 for the rows that
  *   fill whole rounds of the 256 CUs + 5 for the remaining rows (two launches), 8 / 9 = the same with 4 for the remaining rows,
@@ -227,7 +231,7 @@ int sgic_l2norm_u8(const float *d_x, int ldx, int M, int D, float *d_unit, uint8
  *   (global_load_lds: no register pass, no ds_write), the other tiles through registers; all modes are bitwise identical. */
 int sgic_split3_f32(const float *d_x, int ld, int rows, int cols, int seg, int seg_stride, uint16_t *d_planes,
                     sgic_stream_t stream);
-/* planes of a constant W operand [rows = N][cols = K] in the slice-major layout [3][K / 32][N][32] (opts->w_packed = 1 at the
+/* planes of an operand [rows][cols = K] in the slice-major layout [3][K / 32][rows][32] (opts->w_packed / a_packed = 1 at the
  * consuming call): a 16-row piece of a 32-k slice is 1 KiB of consecutive bytes (whole cache lines) for the LDS-DMA staging.  K % 32 == 0. */
 int sgic_split3_pack_f32(const float *d_x, int ld, int rows, int cols, uint16_t *d_planes, sgic_stream_t stream);
 int sgic_gemm_split3_f32(const float *d_A, int lda, int a_seg, int a_seg_stride, uint16_t *d_Aplanes,
@@ -246,14 +250,14 @@ int sgic_groupnorm_nhwc_split3(const float *d_x, const float *d_gamma, const flo
                                sgic_stream_t stream);
 int sgic_halo_copy_split3(const float *d_in, int B, int H, int W, int C, int upsample2x, int tile16, uint16_t *d_halo_planes,
                           sgic_stream_t stream);
-/* sgic_attention_f32 with the output written as bf16x3 planes [3][rows][nheads*64] (rows = the row space of d_rowmap,
+/* sgic_attention_f32 with the output written as slice-major bf16x3 planes [3][nheads*2][rows][32] (rows = the row space of d_rowmap,
  * >= nseq*L): the A operand of the out-projection when that runs as a split GEMM. */
 int sgic_attention_split3_f32(const float *d_q, int ldq, const float *d_k, int ldk, const float *d_v, int ldv,
                               uint16_t *d_out_planes, long rows, int L, int nseq, int nheads, const int32_t *d_rowmap,
                               const float *d_bias, const int32_t *d_biasvar, float scale, const sgic_launch_opts *opts,
                               sgic_stream_t stream);
 /* nn.LayerNorm (call sites as sgic_layernorm_f32) whose only consumer is a split GEMM: the normalised rows are written
- * directly as bf16x3 planes [3][M][C] (dense rows), so no fp32 copy and no separate split pass.  C % 256 == 0, C <= 2048. */
+ * directly as slice-major bf16x3 planes [3][C / 32][M][32] (dense rows), so no fp32 copy and no separate split pass.  C % 256 == 0, C <= 2048. */
 int sgic_layernorm_split3_f32(const float *d_x, int ldx, int xseg, int xseg_stride, const float *d_gamma,
                               const float *d_beta, uint16_t *d_planes, int M, int C, float eps, int act,
                               sgic_stream_t stream);

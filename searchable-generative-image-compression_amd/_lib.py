@@ -22,14 +22,14 @@ c_void_p, c_int, c_float, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
 class LaunchOpts(C.Structure):
     """sgic_launch_opts (include/sgic.h): per-call launch options of the GEMM-family / attention entry points"""
-    _fields_ = [("tile_mode", C.c_int), ("attn_mode", C.c_int), ("profiler", C.c_void_p), ("w_packed", C.c_int)]
+    _fields_ = [("tile_mode", C.c_int), ("attn_mode", C.c_int), ("profiler", C.c_void_p), ("w_packed", C.c_int), ("a_packed", C.c_int)]
 
 
-def launch_opts(tile_mode=0, attn_mode=0, profiler=None, w_packed=0):
+def launch_opts(tile_mode=0, attn_mode=0, profiler=None, w_packed=0, a_packed=0):
     """-> a by-reference ctypes argument, or NULL when every field is at its default"""
-    if not tile_mode and not attn_mode and not profiler and not w_packed:
+    if not tile_mode and not attn_mode and not profiler and not w_packed and not a_packed:
         return c_void_p(0)
-    return C.byref(LaunchOpts(int(tile_mode), int(attn_mode), profiler, int(w_packed)))
+    return C.byref(LaunchOpts(int(tile_mode), int(attn_mode), profiler, int(w_packed), int(a_packed)))
 
 
 class SgicError(RuntimeError):

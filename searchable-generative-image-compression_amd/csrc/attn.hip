@@ -101,7 +101,7 @@ struct AttnArgs {
   int rag;       // ragged query rows per unit computed on the VALU (0, 1 or 2): tokens nq*32 .. L-1
   int n_rag_wgs; // leading blocks that run the ragged-row path (4 rows per block)
   int stagger_cycles, first_round;  // start-up stagger of co-resident workgroups (see attn_f32_kernel), 0 = off
-  unsigned short *out_planes;       // optional: the output as bf16x3 planes [3][rows][nheads*64] (operand of the out-projection
+  unsigned short *out_planes;       // optional: the output as slice-major bf16x3 planes [3][nheads*2][rows][32] (operand of the out-projection
   long plane_elems;                 // split GEMM, gemm_split.hip) instead of `out`; rows * nheads * 64
 };
 
@@ -166,7 +166,7 @@ __device__ void attn_ragged_row(const AttnArgs &a, int unit, int tok, float *wl 
   if (a.out_planes) {
     unsigned p1, p2, p3;
     s3_split_pair(res, 0.f, p1, p2, p3);
-    const size_t dst = (size_t)q_row * (a.nheads * 64) + hc + lane;
+    const size_t dst = s3_pack_off(q_row, hc + lane, a.plane_elems / (a.nheads * 64));
     a.out_planes[dst] = (unsigned short)p1;
     a.out_planes[a.plane_elems + dst] = (unsigned short)p2;
     a.out_planes[2 * a.plane_elems + dst] = (unsigned short)p3;
@@ -610,9 +610,10 @@ __global__ __launch_bounds__(256, (NBUF * UP >= 4 || (S3 && UP > 1)) ? 2 : 3) vo
 #pragma unroll
       for (int t = 0; t < 4; t++) w0[t] = o0[g4 * 4 + t] * inv, w1[t] = o1[g4 * 4 + t] * inv;
       if (a.out_planes) {
-        const size_t dst = (size_t)q_row * (a.nheads * 64) + hc + d;
+        const size_t prows = a.plane_elems / (a.nheads * 64);   // slice-major planes (split3.h): columns hc + d and hc + 32 + d are one slice apart
+        const size_t dst = s3_pack_off(q_row, hc + d, prows);
         s3_store4(a.out_planes, a.plane_elems, dst, w0);
-        s3_store4(a.out_planes, a.plane_elems, dst + 32, w1);
+        s3_store4(a.out_planes, a.plane_elems, dst + prows * 32, w1);
       } else {
         *reinterpret_cast<f32x4 *>(op + d) = w0;
         *reinterpret_cast<f32x4 *>(op + 32 + d) = w1;

@@ -81,6 +81,8 @@ struct S3Args {
   int conv_C, conv_H, conv_W;
   int m_base;                    // logical row of this launch's row 0 (second launch of the split modes 6 / 7): enters the C row map
   int w_packed;                  // W planes are slice-major [3][K / 32][N][32] (sgic_split3_pack_f32) instead of [3][N][K]
+  int a_packed, a_rows;          // A planes are slice-major [3][K / 32][a_rows][32] (split3.h; not for the convolution's halo planes)
+  int c_rows;                    // rows of the Cp planes (slice-major [3][N / 32][c_rows][32]): the whole product's M, also in a split launch
 };
 
 // ---- epilogue of one tile, shared by the register-staged and the LDS-DMA kernel: the accumulators hold
@@ -131,7 +133,7 @@ __device__ __forceinline__ void s3_tile_epilogue(const S3Args &g, f32x4 (&acc)[B
             if constexpr (HASR) v += rv[q];
             if (colok && m < g.M) {
               if constexpr (PLANES) {
-                s3_store4(g.Cp, g.c_plane, (size_t)(m + g.m_base) * g.N + n, v);
+                s3_store4(g.Cp, g.c_plane, s3_pack_off(m + g.m_base, n, g.c_rows), v);
               } else {
                 const int mm = m + g.m_base;
                 const size_t crow = g.c_seg ? (size_t)(mm / g.c_seg) * g.c_seg_stride + (mm % g.c_seg) : (size_t)mm;
@@ -290,6 +292,8 @@ void gemm_split3_kernel(S3Args g) {
       if (g.conv_C) {   // top-left pixel of the 3x3 patch in the halo buffer
         const int hw = g.conv_H * g.conv_W, b = am / hw, r = am - b * hw, y = r / g.conv_W, x = r - y * g.conv_W;
         aptr[i] = g.A + (((size_t)b * (g.conv_H + 2) + y) * (g.conv_W + 2) + x) * g.conv_C + sslot * 8;
+      } else if (g.a_packed) {   // slot sslot of a 64 KS-byte stage row = slice sslot / 4, 16-byte chunk sslot % 4
+        aptr[i] = g.A + ((size_t)(sslot >> 2) * g.a_rows + am) * 32 + (sslot & 3) * 8;
       } else {
         aptr[i] = g.A + (size_t)am * g.K + sslot * 8;
       }
@@ -307,7 +311,7 @@ void gemm_split3_kernel(S3Args g) {
   auto issue = [&](int k0, auto set_c) __attribute__((always_inline)) {
     constexpr int S = decltype(set_c)::value;
     if ((S3_ABLATE & 1) && k0 > 0) return;
-    int ka = k0;
+    size_t ka = g.a_packed ? (size_t)k0 * g.a_rows : (size_t)k0;
     if (g.conv_C) {   // wave-uniform: the tap this K stage belongs to (conv_C % (32 KS) == 0: a stage never straddles a tap)
       const int tap = k0 / g.conv_C, c0 = k0 - tap * g.conv_C, ky = tap / 3, kx = tap - 3 * ky;
       ka = (ky * (g.conv_W + 2) + kx) * g.conv_C + c0;
@@ -620,13 +624,14 @@ void gemm_split3_dma_kernel(S3Args g) {
     return (((size_t)b * (g.conv_H + 2) + y) * (g.conv_W + 2) + x) * g.conv_C;
   };
   auto setup = [&]() __attribute__((always_inline)) {
-    const size_t a0 = g.conv_C ? conv_off(min(m0, g.M - 1)) : (size_t)m0 * g.K;
+    const size_t astride = g.a_packed ? 32 : g.K;   // elements between consecutive rows of a slice
+    const size_t a0 = g.conv_C ? conv_off(min(m0, g.M - 1)) : (size_t)m0 * astride;
     baseA = g.A + a0;
     baseW = g.W + (size_t)n0 * (g.w_packed ? 32 : g.K);
 #pragma unroll
     for (int i = 0; i < CA; i++) {
       const int am = min(m0 + (wave + NW * i) * 16 + prow, g.M - 1);
-      const size_t off = g.conv_C ? conv_off(am) : (size_t)am * g.K;
+      const size_t off = g.conv_C ? conv_off(am) : (size_t)am * astride;
       voffA[i] = (unsigned)((off - a0) * 2 + pslot * 16);
       if ((S3_ABLATE & 192) == 64) voffA[i] = (unsigned)((wave + NW * i) * 1024 + lane * 16);   // diagnostic: bit 6 = operands read as if stored tile-packed (a piece = 1 KiB contiguous); bits 6+7 = W only
     }
@@ -641,7 +646,7 @@ void gemm_split3_dma_kernel(S3Args g) {
   // request K slice k0 of the current tile into LDS stage `buf`: 3 (CA + CW) instructions per wave
   auto dma = [&](int k0, int buf) __attribute__((always_inline)) {
     if ((S3_ABLATE & 1) && k0 > 0) return;
-    int ka = k0;
+    size_t ka = g.a_packed ? (size_t)k0 * g.a_rows : (size_t)k0;
     if (g.conv_C) {   // the tap this K slice belongs to (conv_C % 32 == 0: a slice never straddles a tap)
       const int tap = k0 / g.conv_C, c0 = k0 - tap * g.conv_C, ky = tap / 3, kx = tap - 3 * ky;
       ka = (ky * (g.conv_W + 2) + kx) * g.conv_C + c0;
@@ -649,7 +654,7 @@ void gemm_split3_dma_kernel(S3Args g) {
     unsigned char *stage = smem + buf * STAGE;
 #pragma unroll
     for (int p = 0; p < 3; p++) {
-      const char *pa = reinterpret_cast<const char *>(baseA + p * g.a_plane + (((S3_ABLATE & 192) == 64) ? (k0 / 32) * (TM * 32) : ka));
+      const char *pa = reinterpret_cast<const char *>(baseA + p * g.a_plane + (((S3_ABLATE & 192) == 64) ? (size_t)(k0 / 32) * (TM * 32) : ka));
       const char *pw = reinterpret_cast<const char *>(baseW + p * g.w_plane + ((S3_ABLATE & 64) ? (size_t)(k0 / 32) * (TN * 32) : (g.w_packed ? (size_t)k0 * g.N : (size_t)k0)));
 #pragma unroll
       for (int i = 0; i < CA; i++)
@@ -841,9 +846,10 @@ void gemm_split3_ring_kernel(S3Args g) {
     const bool isA = r < PA;
     const int rw = isA ? min(m0 + r * 16 + prow, g.M - 1) : min(n0 + (r - PA) * 16 + prow, g.N - 1);
     const unsigned short *base = isA ? g.A + p * g.a_plane : g.W + p * g.w_plane;
-    const bool packed = !isA && g.w_packed;
-    src[i] = reinterpret_cast<const char *>(base + (packed ? ((size_t)ks * g.N + rw) * 32 : (size_t)rw * g.K + ks * 32)) + pslot * 16;
-    kmul[i] = packed ? (size_t)g.N * (64 * KS) : (size_t)(64 * KS);   // bytes per K step
+    const bool packed = isA ? g.a_packed != 0 : g.w_packed != 0;
+    const size_t prows = isA ? (size_t)g.a_rows : (size_t)g.N;          // rows of a slice in the slice-major layout
+    src[i] = reinterpret_cast<const char *>(base + (packed ? ((size_t)ks * prows + rw) * 32 : (size_t)rw * g.K + ks * 32)) + pslot * 16;
+    kmul[i] = packed ? prows * (64 * KS) : (size_t)(64 * KS);   // bytes per K step
     dst[i] = (unsigned)(ks * SLICE + (isA ? p * APLANE + r * 1024 : 3 * APLANE + p * WPLANE + (r - PA) * 1024));
   }
   auto dma = [&](int step, int slot) __attribute__((always_inline)) {
@@ -1087,7 +1093,7 @@ static int s3_dispatch(const S3Args &g, const sgic_launch_opts *opts, hipStream_
       S3Args g1 = g, g2 = g;
       g1.M = (int)m_split;
       g2.M = M - (int)m_split;
-      g2.A += m_split * K;          // the planes keep their stride (a_plane); C / R / Cp rows are addressed through m_base
+      g2.A += g.a_packed ? m_split * 32 : m_split * K;   // the planes keep their strides (a_plane, a_rows); C / R / Cp rows are addressed through m_base
       g2.m_base = (int)m_split;
       int rc = s3_mode(g1, big_mode, st, e0, nullptr);
       if (rc) return rc;
@@ -1119,15 +1125,21 @@ extern "C" int sgic_gemm_split3_f32(const float *d_A, int lda, int a_seg, int a_
   SGIC_REQUIRE((d_Cplanes || ldc >= N) && (!d_R || ldr >= N), "leading dimensions");
   SGIC_REQUIRE(act >= 0 && act <= ACT_LRELU, "activation");
   SGIC_REQUIRE(c_seg >= 0 && (c_seg == 0 || c_seg_stride >= c_seg), "row segment map");
-  if (d_A) {
-    int rc = sgic_split3_f32(d_A, lda, M, K, a_seg, a_seg_stride, d_Aplanes, stream);
+  int a_packed = opts ? opts->a_packed : 0;
+  if (d_A) {   // the split pass writes the slice-major layout (the row map is applied on the source side)
+    SGIC_REQUIRE((lda & 3) == 0 && lda >= K && ((uintptr_t)d_A & 15) == 0 && a_seg >= 0 && (a_seg == 0 || a_seg_stride >= a_seg), "A operand");
+    const long total = (long)M * (K >> 3);
+    split3_rows_kernel<true><<<(unsigned)min((total + 255) / 256, 256L * 16), 256, 0, to_stream(stream)>>>(d_A, lda, M, K, a_seg, a_seg_stride, d_Aplanes);
+    int rc = sgic::check_launch("split3_rows_kernel<pack>");
     if (rc) return rc;
+    a_packed = 1;
   }
+  SGIC_REQUIRE(!d_Cplanes || (N & 31) == 0, "planes output needs N % 32 == 0");
   const int vec = (N % 4 == 0) && (!d_bias || ((uintptr_t)d_bias & 15) == 0) && (!d_R || ((ldr % 4 == 0) && ((uintptr_t)d_R & 15) == 0)) &&
                   (d_Cplanes ? ((uintptr_t)d_Cplanes & 7) == 0 : ((ldc % 4 == 0) && ((uintptr_t)d_C & 15) == 0));
   SGIC_REQUIRE(!d_Cplanes || (vec && c_seg == 0), "planes output needs float4-addressable operands and no row map");
   S3Args g{d_Aplanes, d_Wplanes, d_bias, d_R, d_C, M, N, K, ldr, ldc, act, c_seg, c_seg_stride, (long)M * K, (long)N * K, d_Cplanes, (long)M * N, vec, 0, 0, 0, 0,
-           opts ? opts->w_packed : 0};
+           opts ? opts->w_packed : 0, a_packed, M, M};
   return s3_dispatch(g, opts, to_stream(stream));
 }
 
@@ -1147,6 +1159,6 @@ extern "C" int sgic_conv3x3_split3_f32(const uint16_t *d_in_planes, const uint16
   const int vec = (N % 4 == 0) && (!d_bias || ((uintptr_t)d_bias & 15) == 0) && (!d_R || ((ldr % 4 == 0) && ((uintptr_t)d_R & 15) == 0)) &&
                   (ldc % 4 == 0) && ((uintptr_t)d_out & 15) == 0;
   S3Args g{d_in_planes, d_Wplanes, d_bias, d_R, d_out, M, N, K, ldr, ldc, act, 0, 0, halo_rows * Cin, (long)N * K, nullptr, 0, vec, Cin, H, W, 0,
-           opts ? opts->w_packed : 0};
+           opts ? opts->w_packed : 0, 0, 0, 0};
   return s3_dispatch(g, opts, to_stream(stream));
 }

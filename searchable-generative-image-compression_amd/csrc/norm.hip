@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     f32x4 o;
 #pragma unroll
     for (int t = 0; t < 4; t++) o[t] = act_f((v[i][t] - mean) * rstd * g[t] + b[t], act);
-    if (planes) s3_store4(planes, (long)M * C, (size_t)m * C + c, o);
+    if (planes) s3_store4(planes, (long)M * C, s3_pack_off(m, c, M), o);
     else *reinterpret_cast<f32x4 *>(yp + c) = o;
   }
 }

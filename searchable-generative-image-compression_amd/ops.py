@@ -49,9 +49,9 @@ def profile_end():
     return [(fl, float(buf[i]), key) for i, (fl, key) in enumerate(recs)]
 
 
-def _opts(tile=0, attn=0, prof=None, w_packed=0):
+def _opts(tile=0, attn=0, prof=None, w_packed=0, a_packed=0):
     """prof: an explicit profiler handle (the tuner's probes); default: the bench's window when one is open"""
-    return launch_opts(tile, attn, prof if prof is not None else (_PROFILER if PROFILE is not None else None), w_packed)
+    return launch_opts(tile, attn, prof if prof is not None else (_PROFILER if PROFILE is not None else None), w_packed, a_packed)
 
 
 def _rows(t):
@@ -347,8 +347,9 @@ def set_precision(p):
 
 
 class Planes:
-    """an activation held as bf16x3 planes [3, rows, cols] (int16 bit patterns): the A operand of a split GEMM written
-    directly by its producer (layernorm / gemm epilogue), so no fp32 copy and no separate split pass exists"""
+    """an activation held as bf16x3 planes (int16 bit patterns) in the slice-major layout [3, cols / 32, rows, 32] (csrc/split3.h):
+    the A operand of a split GEMM written directly by its producer (layernorm / attention / gemm epilogue / split3_planes), so no
+    fp32 copy and no separate split pass exists"""
     __slots__ = ("t", "rows", "cols")
 
     def __init__(self, rows, cols, device, buf=None):
@@ -367,9 +368,14 @@ class Planes:
     def device(self):
         return self.t.device
 
+    def rowmajor(self):
+        """the planes as a [3, rows, cols] tensor (tests / debugging): what ops.split3 returns for the same values"""
+        p = self.t[:3 * self.rows * self.cols].view(3, self.cols // 32, self.rows, 32)
+        return p.permute(0, 2, 1, 3).reshape(3, self.rows, self.cols)
+
     def float(self):
         """the fp32 values (tests / debugging): the sum of the three planes"""
-        p = self.t[:3 * self.rows * self.cols].view(3, self.rows, self.cols)
+        p = self.rowmajor()
         f = lambda q: (q.to(torch.int32) << 16).view(torch.float32)
         return (f(p[0]) + f(p[1])) + f(p[2])
 
@@ -388,6 +394,16 @@ def split3(x, ld=None, rows=None, seg=(0, 0), out=None):
         out = torch.empty(3, rows, cols, device=x.device, dtype=torch.int16)
     call("sgic_split3_f32", _p(x), ldx if ld is None else ld, rows, cols, seg[0], seg[1], _p(out))
     return out
+
+
+def split3_planes(x, out=None):
+    """x[rows, cols] fp32 -> a Planes object (slice-major layout): a pre-split A operand for gemm()"""
+    x, ldx = _rows(x)
+    rows, cols = x.shape
+    assert cols % 32 == 0
+    pl = out if isinstance(out, Planes) and out.shape == (rows, cols) else Planes(rows, cols, x.device)
+    call("sgic_split3_pack_f32", _p(x), ldx, rows, cols, _p(pl.t))
+    return pl
 
 
 def weight_planes(w, ldw):
@@ -479,7 +495,7 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, M=None, a_seg=(
 
         def launch3(mode, prof=None):
             call("sgic_gemm_split3_f32", _p(a_f32), lda, a_seg[0], a_seg[1], _p(ap), _p(wp), _p(bias), _p(residual), ldr, _p(out), ldc,
-                 _p(cp), M, N, K, act, c_seg[0], c_seg[1], _opts(tile=mode, prof=prof, w_packed=1))
+                 _p(cp), M, N, K, act, c_seg[0], c_seg[1], _opts(tile=mode, prof=prof, w_packed=1, a_packed=1))
 
         if tile is not None:
             launch3(tile)

@@ -148,7 +148,7 @@ def test_planes_producers_match_the_two_step_path(ops):
             torch.cuda.synchronize()
             # the same planes as the split pass makes of the fp32 output (tiny GELU tails, < 1e-30, lose their subnormal low pieces
             # either way, so the comparison is between the planes, not with f itself)
-            assert isinstance(f_pl, ops.Planes) and torch.equal(f_pl.t.view(3, M, N), ops.split3(f))
+            assert isinstance(f_pl, ops.Planes) and torch.equal(f_pl.rowmajor(), ops.split3(f))
             assert float((f_pl.float() - f).abs().max()) < 1e-30
             y_pl = ops.gemm(f_pl, w2, residual=x, tile=tile)
             y = ops.gemm(f, w2, residual=x, tile=tile)
@@ -177,7 +177,7 @@ def test_attention_planes_output(ops, L, nseq, heads):
         pl = ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], None, L, nseq, heads, to_gemm=True)
         torch.cuda.synchronize()
         assert isinstance(pl, ops.Planes) and torch.is_tensor(ref)
-        assert torch.equal(pl.t.view(3, nseq * L, D), ops.split3(ref))
+        assert torch.equal(pl.rowmajor(), ops.split3(ref))
     finally:
         ops.set_precision(old)
 
@@ -223,8 +223,7 @@ def test_single_tile_latency(ops):
     that no producer kernel sits in front of the timed dispatch."""
     a = torch.randn(64, 512, device="cuda")
     w = torch.randn(64, 512, device="cuda")
-    ap = ops.Planes(64, 512, a.device)            # pre-split: the timed dispatch has no split3_rows_kernel in front of it
-    ops.split3(a, out=ap.t)
+    ap = ops.split3_planes(a)                     # pre-split: the timed dispatch has no split3_rows_kernel in front of it
     for _ in range(10):
         ops.gemm(ap, w, precision="split3", tile=4)
     torch.cuda.synchronize()
@@ -256,23 +255,25 @@ def test_edge_shapes_every_mode(ops, M, N, K):
         assert torch.equal(out, first), tile
 
 
-def test_row_major_and_slice_major_weight_planes_agree(ops):
-    """W planes in the plain [3][N][K] layout (sgic_split3_f32, opts->w_packed = 0: what a C caller without the packing pass hands
-    over) and in the slice-major layout ops.gemm uses (sgic_split3_pack_f32, w_packed = 1) give bitwise the same product, for a
-    register-staged tile (5), an LDS-DMA tile (1) and the ring kernel (19, 23)"""
+def test_row_major_and_slice_major_planes_agree(ops):
+    """A and W planes in the plain row-major layouts [3][M][K] / [3][N][K] (sgic_split3_f32, opts->a_packed = w_packed = 0: what a C
+    caller without the packing pass hands over) and in the slice-major layout ops.gemm uses (sgic_split3_pack_f32 and the producers'
+    outputs, a_packed = w_packed = 1) give bitwise the same product in every combination, for a register-staged tile (5, 4), an
+    LDS-DMA tile (1), the ring kernel (19, 23) and a two-launch mode (8: the second launch starts inside the A planes)"""
     from sgic_amd._lib import call, launch_opts
     from sgic_amd.ops import _p
     g = torch.Generator(device="cuda").manual_seed(5)
-    M, N, K = 600, 520, 448
+    M, N, K = 11200, 520, 448     # 88 x 3 tiles of 128x256: mode 8 = 85 whole m-tiles (one round of 256 CUs) + a second launch from row 10880
     a = torch.randn(M, K, device="cuda", generator=g)
     w = torch.randn(N, K, device="cuda", generator=g) * 0.1
     bias = torch.randn(N, device="cuda", generator=g)
     ref = ops.gemm(a, w, bias, precision="split3", tile=2)
-    ap = ops.split3(a)
-    wp = ops.split3(w)                       # row-major planes
-    for tile in (1, 5, 19, 23, 4):
-        out = torch.empty(M, N, device="cuda")
-        call("sgic_gemm_split3_f32", None, 0, 0, 0, _p(ap), _p(wp), _p(bias), None, 0, _p(out), N, None, M, N, K, 0, 0, 0,
-             launch_opts(tile, 0, None, 0))
-        torch.cuda.synchronize()
-        assert torch.equal(out, ref), tile
+    planes = {(0, "a"): ops.split3(a), (0, "w"): ops.split3(w), (1, "a"): ops.split3_planes(a).t, (1, "w"): ops.split3_planes(w).t}
+    for tile in (1, 5, 19, 23, 4, 8):
+        for apk in (0, 1):
+            for wpk in (0, 1):
+                out = torch.empty(M, N, device="cuda")
+                call("sgic_gemm_split3_f32", None, 0, 0, 0, _p(planes[apk, "a"]), _p(planes[wpk, "w"]), _p(bias), None, 0, _p(out), N, None,
+                     M, N, K, 0, 0, 0, launch_opts(tile, 0, None, wpk, apk))
+                torch.cuda.synchronize()
+                assert torch.equal(out, ref), (tile, apk, wpk)

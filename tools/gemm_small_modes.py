@@ -35,8 +35,7 @@ def main():
         w = torch.randn(N, K, device=dev, generator=g) * 0.03
         b = torch.randn(N, device=dev, generator=g)
         r = torch.randn(M, N, device=dev, generator=g) if res else None
-        ap = ops.Planes(M, K, dev)
-        ops.split3(a, out=ap.t.view(3, M, K))
+        ap = ops.split3_planes(a)
         row = []
         for mode in (13, 15):
             row.append(timed(lambda: ops.gemm(a, w, b, residual=r, act=act, tile=mode, precision="f32")))

@@ -26,8 +26,7 @@ side = torch.cuda.Stream(device=dev)
 M, N, K = 9248, 4096, 1024
 a = torch.randn(M, K, device=dev)
 w = torch.randn(N, K, device=dev) * 0.03
-ap = ops.Planes(M, K, dev)
-ops.split3(a, out=ap.t.view(3, M, K))
+ap = ops.split3_planes(a)
 out = torch.empty(M, N, device=dev)
 
 

@@ -67,8 +67,7 @@ def main():
             w = torch.randn(N, K, device=dev, generator=g) * 0.03
             b = torch.randn(N, device=dev, generator=g)
             r = torch.randn(M, N, device=dev, generator=g) if res else None
-            ap = ops.Planes(M, K, dev)
-            ops.split3(a, out=ap.t.view(3, M, K))
+            ap = ops.split3_planes(a)
             out = torch.empty(M, N, device=dev)
             modes = list(SMALL_MODES) if SMALL else [m for m in GEMM_MODES if not (m in (1, 6, 8, 10, 12) and N < 256)]
             t = race(lambda m: ops.gemm(ap, w, b, residual=r, act=act, out=out, tile=m, precision="split3"), modes)
