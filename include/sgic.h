@@ -238,13 +238,16 @@ int sgic_gemm_split3_f32(const float *d_A, int lda, int a_seg, int a_seg_stride,
                          const uint16_t *d_Wplanes, const float *d_bias, const float *d_R, int ldr, float *d_C, int ldc,
                          uint16_t *d_Cplanes, int M, int N, int K, int act, int c_seg, int c_seg_stride,
                          const sgic_launch_opts *opts, sgic_stream_t stream);
-/* sgic_conv3x3_f32 as an implicit split GEMM: d_in_planes = bf16x3 planes [3][B (H+2) (W+2)][Cin] of the zero-halo NHWC
- * input (sgic_split3_f32 over the halo buffer's rows), d_Wplanes = planes [3][Cout][9 Cin].  Cin % 32 == 0. */
+/* sgic_conv3x3_f32 as an implicit split GEMM: d_in_planes = bf16x3 planes of the zero-halo NHWC input, [3][B (H+2) (W+2)][Cin]
+ * (sgic_split3_f32 over the halo buffer's rows; opts->a_packed = 0) or slice-major [3][Cin / 32][B (H+2) (W+2)][32]
+ * (sgic_split3_pack_f32, sgic_groupnorm_nhwc_split3, sgic_halo_copy_split3; a_packed = 1); d_Wplanes = planes [3][Cout][9 Cin]
+ * (or slice-major, w_packed = 1).  Cin % 32 == 0. */
 int sgic_conv3x3_split3_f32(const uint16_t *d_in_planes, const uint16_t *d_Wplanes, const float *d_bias, const float *d_R,
                             int ldr, float *d_out, int ldc, int B, int H, int W, int Cin, int Cout, int act,
                             const sgic_launch_opts *opts, sgic_stream_t stream);
-/* sgic_groupnorm_nhwc / sgic_halo_copy writing the interior of a zero-halo bf16x3 planes buffer
- * [3][B (H+2) (W+2)][C] -- the input of sgic_conv3x3_split3_f32 -- directly (no fp32 halo buffer, no split pass). */
+/* sgic_groupnorm_nhwc / sgic_halo_copy writing the interior of a zero-halo slice-major bf16x3 planes buffer
+ * [3][C / 32][B (H+2) (W+2)][32] -- the input of sgic_conv3x3_split3_f32 with a_packed = 1 -- directly (no fp32 halo buffer, no
+ * split pass).  C % 32 == 0. */
 int sgic_groupnorm_nhwc_split3(const float *d_x, const float *d_gamma, const float *d_beta, int B, int H, int W, int C,
                                int groups, float eps, int swish, double *d_ws, float *d_stats, uint16_t *d_halo_planes,
                                sgic_stream_t stream);

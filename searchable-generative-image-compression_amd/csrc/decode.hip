@@ -124,9 +124,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
       if (swish) r = r / (1.0f + __expf(-r));  // x * sigmoid(x)
       o[e] = r;
     }
-    if (planes) {   // halo output as bf16x3 planes [3][B (H+2) (W+2)][C]: the operand of an implicit split-GEMM convolution
+    if (planes) {   // halo output as slice-major bf16x3 planes [3][C / 32][B (H+2) (W+2)][32]: the operand of an implicit split-GEMM convolution
       const long prow = ((long)b * (H + 2) + yy + 1) * (W + 2) + 1 + xx;
-      s3_store4(planes, (long)B * (H + 2) * (W + 2) * C, (size_t)prow * C + c4 * 4, o);
+      s3_store4(planes, (long)B * (H + 2) * (W + 2) * C, s3_pack_off(prow, c4 * 4, (size_t)B * (H + 2) * (W + 2)), o);
     } else {
       reinterpret_cast<f32x4 *>(yr + (long)xx * C)[c4] = o;
     }
@@ -192,7 +192,7 @@ __global__ void halo_copy_kernel(const float *__restrict__ in, int B, int H, int
     const long irow = tile16 ? tm16_row(b, sy, sx, H, W) : ((long)b * H + sy) * W + sx;
     const f32x4 v = reinterpret_cast<const f32x4 *>(in + irow * C)[c4];
     const long prow = ((long)b * (OH + 2) + oy + 1) * (OW + 2) + ox + 1;
-    if (planes) s3_store4(planes, (long)B * (OH + 2) * (OW + 2) * C, (size_t)prow * C + c4 * 4, v);
+    if (planes) s3_store4(planes, (long)B * (OH + 2) * (OW + 2) * C, s3_pack_off(prow, c4 * 4, (size_t)B * (OH + 2) * (OW + 2)), v);
     else reinterpret_cast<f32x4 *>(out + prow * C)[c4] = v;
   }
 }

@@ -81,7 +81,7 @@ struct S3Args {
   int conv_C, conv_H, conv_W;
   int m_base;                    // logical row of this launch's row 0 (second launch of the split modes 6 / 7): enters the C row map
   int w_packed;                  // W planes are slice-major [3][K / 32][N][32] (sgic_split3_pack_f32) instead of [3][N][K]
-  int a_packed, a_rows;          // A planes are slice-major [3][K / 32][a_rows][32] (split3.h; not for the convolution's halo planes)
+  int a_packed, a_rows;          // A planes are slice-major [3][K / 32][a_rows][32] (split3.h); convolution: [3][conv_C / 32][a_rows = halo rows][32]
   int c_rows;                    // rows of the Cp planes (slice-major [3][N / 32][c_rows][32]): the whole product's M, also in a split launch
 };
 
@@ -291,7 +291,8 @@ void gemm_split3_kernel(S3Args g) {
       const int am = min(m0 + srow + i * (NT / SL), g.M - 1);
       if (g.conv_C) {   // top-left pixel of the 3x3 patch in the halo buffer
         const int hw = g.conv_H * g.conv_W, b = am / hw, r = am - b * hw, y = r / g.conv_W, x = r - y * g.conv_W;
-        aptr[i] = g.A + (((size_t)b * (g.conv_H + 2) + y) * (g.conv_W + 2) + x) * g.conv_C + sslot * 8;
+        const size_t pix = ((size_t)b * (g.conv_H + 2) + y) * (g.conv_W + 2) + x;
+        aptr[i] = g.a_packed ? g.A + ((size_t)(sslot >> 2) * g.a_rows + pix) * 32 + (sslot & 3) * 8 : g.A + pix * g.conv_C + sslot * 8;
       } else if (g.a_packed) {   // slot sslot of a 64 KS-byte stage row = slice sslot / 4, 16-byte chunk sslot % 4
         aptr[i] = g.A + ((size_t)(sslot >> 2) * g.a_rows + am) * 32 + (sslot & 3) * 8;
       } else {
@@ -314,7 +315,7 @@ void gemm_split3_kernel(S3Args g) {
     size_t ka = g.a_packed ? (size_t)k0 * g.a_rows : (size_t)k0;
     if (g.conv_C) {   // wave-uniform: the tap this K stage belongs to (conv_C % (32 KS) == 0: a stage never straddles a tap)
       const int tap = k0 / g.conv_C, c0 = k0 - tap * g.conv_C, ky = tap / 3, kx = tap - 3 * ky;
-      ka = (ky * (g.conv_W + 2) + kx) * g.conv_C + c0;
+      ka = g.a_packed ? ((size_t)(c0 >> 5) * g.a_rows + ky * (g.conv_W + 2) + kx) * 32 : (size_t)((ky * (g.conv_W + 2) + kx) * g.conv_C + c0);
     }
     const size_t kw = g.w_packed ? (size_t)k0 * g.N : (size_t)k0;   // packed: slice k0 / 32 starts (k0 / 32) N 32 elements in
 #pragma unroll
@@ -621,7 +622,7 @@ void gemm_split3_dma_kernel(S3Args g) {
   const unsigned short *baseA, *baseW;    // uniform: plane 0, K offset 0, tile row 0
   auto conv_off = [&](int am) __attribute__((always_inline)) {   // element offset of logical row am's top-left halo pixel
     const int hw = g.conv_H * g.conv_W, b = am / hw, r = am - b * hw, y = r / g.conv_W, x = r - y * g.conv_W;
-    return (((size_t)b * (g.conv_H + 2) + y) * (g.conv_W + 2) + x) * g.conv_C;
+    return (((size_t)b * (g.conv_H + 2) + y) * (g.conv_W + 2) + x) * (g.a_packed ? 32 : g.conv_C);
   };
   auto setup = [&]() __attribute__((always_inline)) {
     const size_t astride = g.a_packed ? 32 : g.K;   // elements between consecutive rows of a slice
@@ -649,7 +650,7 @@ void gemm_split3_dma_kernel(S3Args g) {
     size_t ka = g.a_packed ? (size_t)k0 * g.a_rows : (size_t)k0;
     if (g.conv_C) {   // the tap this K slice belongs to (conv_C % 32 == 0: a slice never straddles a tap)
       const int tap = k0 / g.conv_C, c0 = k0 - tap * g.conv_C, ky = tap / 3, kx = tap - 3 * ky;
-      ka = (ky * (g.conv_W + 2) + kx) * g.conv_C + c0;
+      ka = g.a_packed ? ((size_t)(c0 >> 5) * g.a_rows + ky * (g.conv_W + 2) + kx) * 32 : (size_t)((ky * (g.conv_W + 2) + kx) * g.conv_C + c0);
     }
     unsigned char *stage = smem + buf * STAGE;
 #pragma unroll
@@ -1032,7 +1033,8 @@ static int s3_launch_ring(const S3Args &g, hipStream_t st, hipEvent_t ev_start, 
 // and is ALSO offered with DMA staging as modes 16 / 17 for the tuner (short-K shapes gain 2-4 %).
 static int s3_mode(const S3Args &g, int mode, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
   // a DMA piece is addressed by per-lane 32-bit byte offsets from the tile's base: true for every tile below unless rows are absurdly long
-  const bool dma_ok = (size_t)g.K * 2 * 256 < (1ull << 31) && (!g.conv_C || (size_t)(g.conv_W + 2) * g.conv_C * 2 * 1024 < (1ull << 31));
+  const bool dma_ok = (size_t)(g.a_packed ? 32 : g.K) * 2 * 256 < (1ull << 31) && (size_t)(g.w_packed ? 32 : g.K) * 2 * 256 < (1ull << 31) &&
+                      (!g.conv_C || (size_t)(g.conv_W + 2) * (g.a_packed ? 32 : g.conv_C) * 2 * 1024 < (1ull << 31));
   switch (mode) {
     case 1: return dma_ok ? s3_launch_dma<2, 4, 4, 4>(g, st, e0, e1) : s3_launch<2, 4, 2, 2, 1>(g, st, e0, e1);
     case 10: return dma_ok ? s3_launch_dma<2, 4, 4, 4, true>(g, st, e0, e1) : s3_launch<2, 4, 2, 2, 1>(g, st, e0, e1);
@@ -1159,6 +1161,6 @@ extern "C" int sgic_conv3x3_split3_f32(const uint16_t *d_in_planes, const uint16
   const int vec = (N % 4 == 0) && (!d_bias || ((uintptr_t)d_bias & 15) == 0) && (!d_R || ((ldr % 4 == 0) && ((uintptr_t)d_R & 15) == 0)) &&
                   (ldc % 4 == 0) && ((uintptr_t)d_out & 15) == 0;
   S3Args g{d_in_planes, d_Wplanes, d_bias, d_R, d_out, M, N, K, ldr, ldc, act, 0, 0, halo_rows * Cin, (long)N * K, nullptr, 0, vec, Cin, H, W, 0,
-           opts ? opts->w_packed : 0, 0, 0, 0};
+           opts ? opts->w_packed : 0, opts ? opts->a_packed : 0, (int)halo_rows, 0};
   return s3_dispatch(g, opts, to_stream(stream));
 }

@@ -35,5 +35,6 @@ __device__ __forceinline__ void s3_store4(unsigned short *planes, long plane_ele
 // ---- slice-major ("packed") plane layout [3][cols / 32][rows][32]: the 64 bytes a row contributes to a 32-k slice sit next to the
 // neighbouring rows' (16 rows of a slice = 1 KiB of consecutive bytes: whole cache lines for the GEMM's LDS-DMA pieces) instead of
 // 2 cols bytes apart.  Every producer of an A operand (LayerNorm, attention, the GEMM epilogue, the split pass inside the GEMM entry
-// point) writes it; the row-major layout [3][rows][cols] remains for the convolution's halo planes and for C callers (opts->a_packed = 0).
+// point, the GroupNorm / halo-copy writers of the convolution's halo planes) writes it; the row-major layout [3][rows][cols] remains for
+// C callers that split with sgic_split3_f32 (opts->a_packed = 0).
 __device__ __forceinline__ size_t s3_pack_off(size_t row, int col, size_t rows) { return ((size_t)(col >> 5) * rows + row) * 32 + (col & 31); }

@@ -753,8 +753,8 @@ def gemm_batched(a, lda, sa, w, ldw, sw, out, ldc, sc, M, N, K, batch, bias=None
 
 
 class HaloPlanes:
-    """the zero-halo input of a 3x3 convolution held as bf16x3 planes [3, B (H+2) (W+2), C] (int16 bit patterns), written
-    directly by groupnorm / halo_copy when the convolution runs as an implicit split GEMM"""
+    """the zero-halo input of a 3x3 convolution held as slice-major bf16x3 planes [3, C / 32, B (H+2) (W+2), 32] (int16 bit patterns),
+    written directly by groupnorm / halo_copy when the convolution runs as an implicit split GEMM"""
     __slots__ = ("t", "B", "H", "W", "C")
 
     def __init__(self, t, B, H, W, C):
@@ -803,11 +803,11 @@ def conv3x3(x_halo, w, bias, B, H, W, Cin, Cout, residual=None, act=ACT_NONE, ou
             ws = hp.t
         else:
             ws = _a3_workspace(dev, 3 * rows * Cin)
-            call("sgic_split3_f32", _p(x_halo), Cin, rows, Cin, 0, 0, _p(ws))
+            call("sgic_split3_pack_f32", _p(x_halo), Cin, rows, Cin, _p(ws))
 
         def launch3(mode, prof=None):
             call("sgic_conv3x3_split3_f32", _p(ws), _p(wp), _p(bias), _p(residual), ldr, _p(out), ldc, B, H, W, Cin, Cout, act,
-                 _opts(tile=mode, prof=prof, w_packed=1))
+                 _opts(tile=mode, prof=prof, w_packed=1, a_packed=1))
 
         if tile is not None:
             launch3(tile)

@@ -83,7 +83,7 @@ def main():
             b = torch.randn(Cout, device=dev, generator=g)
             r = torch.randn(M, Cout, device=dev, generator=g) if res else None
             hp = ops.halo_planes_buffer(dev, B, H, W, Cin)
-            ops.split3(halo.view(-1, Cin), out=hp.t.view(3, -1, Cin))
+            ops.split3_planes(halo.view(-1, Cin), out=ops.Planes(halo.numel() // Cin, Cin, dev, buf=hp.t))
             out = torch.empty(M, Cout, device=dev)
             modes = [m for m in CONV_MODES if not (m in (1, 10) and Cout < 256)]
             t = race(lambda m: ops.conv3x3(hp, w, b, B, H, W, Cin, Cout, residual=r, act=act, out=out, tile=m, precision="split3"), modes)
