@@ -122,9 +122,11 @@ int sgic_dequant_step(const int16_t *d_sym, const float *d_means, int ld_sm, flo
  *     otherwise runs as 13).  Results are bitwise identical for
  *     every choice (the k order is fixed by K alone); the host autotuner (sgic_amd.ops) picks per shape and persists
  *     its picks.
- *   attn_mode (sgic_attention_f32): low 3 bits: 0 = built-in choice, 1..6 = K/V ring depth x start-up stagger (results bitwise
- *     identical for every choice); +8: S^T = K Q^T as a bf16x3 split product on the bf16 matrix pipe (fp32-accurate, the
- *     arithmetic of sgic_gemm_split3_f32; differs from the fp32-MFMA variant in the last bits, identical across 1..6).
+ *   attn_mode (sgic_attention_f32): low 3 bits: 0 = built-in choice, 1..6 = K/V ring depth x start-up stagger, 7 = three query
+ *     row blocks per workgroup with a unit's row blocks padded to a multiple of three (three workgroups per CU: two whole rounds
+ *     for L = 289 at batch 32) (results bitwise identical for every choice); +8: S^T = K Q^T as a bf16x3 split product on the bf16
+ *     matrix pipe (fp32-accurate, the arithmetic of sgic_gemm_split3_f32; differs from the fp32-MFMA variant in the last bits,
+ *     identical across 1..7).
  *   profiler: non-NULL and open => the launch is dispatched with its own (start, stop) event pair (hipExtLaunchKernel:
  *     timestamps taken by the dispatch itself, no extra packets on the stream). */
 typedef struct sgic_profiler sgic_profiler;

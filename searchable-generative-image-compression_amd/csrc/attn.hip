@@ -95,7 +95,8 @@ struct AttnArgs {
   float scale;
   int nq;        // 32-row query blocks per unit handled on the matrix cores
   int ipw;       // items per workgroup (4, or 2 when nq == 1 so that a workgroup never spans more than 2 units)
-  int n_items;   // nseq * nheads * nq
+  int nqp;       // row-block slots per unit, >= nq (nq padded to a multiple of ipw: a workgroup then never spans two units)
+  int n_items;   // nseq * nheads * nqp
   int n_wgs;     // MFMA workgroups (logical)
   int group;     // consecutive logical workgroups dealt to one XCD
   int rag;       // ragged query rows per unit computed on the VALU (0, 1 or 2): tokens nq*32 .. L-1
@@ -215,13 +216,14 @@ __global__ __launch_bounds__(256, (NBUF * UP >= 4 || (S3 && UP > 1)) ? 2 : 3) vo
 
   AT_STAMP(0);
   const int item0 = wg * a.ipw;
-  const int uA = item0 / a.nq;
+  const int uA = item0 / a.nqp;
   const int last = min(item0 + a.ipw, a.n_items) - 1;
-  const bool two = UP > 1 && (last / a.nq) != uA;            // workgroup-uniform: a second unit is present
+  const bool two = UP > 1 && (last / a.nqp) != uA;           // workgroup-uniform: a second unit is present
   const int item = item0 + wave;
-  const bool active = wave < a.ipw && item < a.n_items;      // wave-uniform
-  const int unit = active ? item / a.nq : uA;
-  const int rb = active ? item - unit * a.nq : 0;
+  const int unit_i = item / a.nqp, rb_i = item - unit_i * a.nqp;
+  const bool active = wave < a.ipw && item < a.n_items && rb_i < a.nq;   // wave-uniform (rb_i >= nq: a padding slot of mode 7)
+  const int unit = active ? unit_i : uA;
+  const int rb = active ? rb_i : 0;
   const int mine = (UP > 1 && unit != uA) ? 1 : 0;           // which staged region this wave reads
   const int head = unit % a.nheads, seq = unit / a.nheads;
 
@@ -643,30 +645,36 @@ static int attention_any(const float *d_q, int ldq, const float *d_k, int ldk, c
   // (one barrier per tile); modes 3,4 / 5,6 add the start-up stagger of 4096 / 8192 cycles per hardware wave slot.
   // bit 3 (+8): S^T = K . Q^T as a bf16x3 split product on the bf16 matrix pipe (fp32-accurate; results differ in the last bits
   // from the fp32-MFMA variant, and are again identical for every mode of the same variant)
-  SGIC_REQUIRE(mode_all >= 0 && mode_all <= 14 && (mode_all & 7) <= 6, "attn_mode 0..6 (+8)");
+  // mode 7: THREE row blocks per workgroup with the unit's row blocks padded to a multiple of three (single buffer, no stagger): a
+  // workgroup never spans two units, so it runs the one-unit kernel at three workgroups per CU -- 9 computing waves per CU.  For
+  // L = 289 (9 row blocks x 512 units at batch 32) that is exactly two rounds of the 768 resident workgroups instead of 2.25 rounds
+  // of 512 (whose last round runs a quarter full); L = 545 (17 -> 18 slots): three rounds instead of 3.19.
+  SGIC_REQUIRE(mode_all >= 0 && mode_all <= 15, "attn_mode 0..7 (+8)");
   const bool s3 = (mode_all & 8) != 0;
   const int mode = mode_all & 7;
   const long units = (long)nseq * nheads;
   const int rem = L % 32;
   const int rag = (rem >= 1 && rem <= 2 && L >= 64 && L <= AT_RAG_MAXL) ? rem : 0;   // ragged query rows -> VALU path
   const int nq = rag ? L / 32 : (L + 31) / 32;
-  const int ipw = nq == 1 ? 2 : 4;
-  const long n_items = units * nq;
+  const bool three = mode == 7 && nq >= 2;
+  const int ipw = three ? 3 : (nq == 1 ? 2 : 4);
+  const int nqp = three ? (nq + 2) / 3 * 3 : nq;
+  const long n_items = units * nqp;
   SGIC_REQUIRE(n_items < (1l << 30), "too many (sequence, head, row block) items");
   const int n_wgs = (int)((n_items + ipw - 1) / ipw);
-  const int group = (4 * nq) / ipw;                      // workgroups that cover 4 whole units
+  const int group = (4 * nqp) / ipw;                     // workgroups that cover 4 whole units
   const long groups = (n_wgs + group - 1) / group;
   const long grid_mfma = ((groups + 7) / 8) * 8 * group;
   const int n_rag_wgs = (int)((units * rag + 3) / 4);
-  const bool up2 = (nq % ipw) != 0;
+  const bool up2 = (nqp % ipw) != 0;
   AttnArgs a{d_q, d_k, d_v, d_out, ldq, ldk, ldv, ldo, L, nseq, nheads, d_rowmap, d_bias, d_biasvar, scale,
-             nq, ipw, (int)n_items, n_wgs, group, rag, n_rag_wgs, 0, 0, d_planes, plane_rows * nheads * 64};
+             nq, ipw, nqp, (int)n_items, n_wgs, group, rag, n_rag_wgs, 0, 0, d_planes, plane_rows * nheads * 64};
   const unsigned grid = (unsigned)(grid_mfma + n_rag_wgs);
   hipStream_t st = to_stream(stream);
   // default (mode 0), from the round-2 measurements (tools/bench_attn.py, tools/micro/attn_stamps.hip): a single K/V buffer
   // (3 workgroups per CU) with the 8192-cycle start-up stagger when workgroups span two units (L = 289, 545), the plain
   // single buffer otherwise (L = 256 windows, the CLIP towers)
-  const int eff = mode ? mode : (up2 ? 5 : 1);
+  const int eff = three ? 1 : (mode ? (mode == 7 ? 1 : mode) : (up2 ? 5 : 1));
   const bool single = (eff & 1) != 0;
   // first dispatch round = what is resident at once: workgroups per CU (LDS / register limited) x 256 CUs
   a.stagger_cycles = eff > 2 ? 4096 * ((eff - 1) / 2) : 0;

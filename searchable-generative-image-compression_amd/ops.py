@@ -84,7 +84,7 @@ def empty(*shape, like=None, dtype=torch.float32, device=None):
 # AUTOTUNE = False uses the cache / built-in heuristic only.  Single-threaded by design (one launching thread).
 AUTOTUNE = True
 TUNE_MODES = (1, 2, 3, 4, 5, 7, 9, 10, 11, 12, 13, 14, 15)   # {128x128, 128x64} x {double, single LDS buffer}, staggered wide, mixed 128x128 + 64x64 tail, persistent (plain, mixed), 64x64, 16x16x4 latency kernel
-ATTN_MODES = (1, 2, 3, 4, 5, 6)                            # {single, double}-buffered K/V ring x start-up stagger {0, 4096, 8192} cycles
+ATTN_MODES = (1, 2, 3, 4, 5, 6, 7)                         # {single, double}-buffered K/V ring x start-up stagger {0, 4096, 8192} cycles; 7 = three row blocks per workgroup
 _TILE = {}        # key -> mode (exact shapes)
 _FAMILY = {}      # key without M -> {M: mode}
 _DIRTY = False
@@ -102,7 +102,7 @@ def _remember(key, mode, dirty=True):
     _DIRTY = _DIRTY or dirty
 
 
-_MAX_MODE = {"gemm": 15, "conv3x3": 15, "gemm3": 25, "conv3": 25, "attn": 6, "attn3": 6}   # per kind of key
+_MAX_MODE = {"gemm": 15, "conv3x3": 15, "gemm3": 25, "conv3": 25, "attn": 7, "attn3": 7}   # per kind of key
 
 
 def _load_tile_cache():
