@@ -13,7 +13,7 @@ for (L, nseq, heads, bias) in [(289, 32, 16, False), (545, 32, 12, False), (256,
     b = torch.randn(1, L, L, device=dev) if bias else None
     fl = 4.0 * L * L * 64 * heads * nseq
     res = []
-    for mw in tuple(int(x) for x in os.environ.get("MODES", "1,2,3,4,5,6").split(",")):
+    for mw in tuple(int(x) for x in os.environ.get("MODES", "1,2,3,4,5,6,7").split(",")):
         for _ in range(3):
             ops.attention(qkv[:, :D], qkv[:, D:2*D], qkv[:, 2*D:], out, L, nseq, heads, bias=b, mode=mw)
         torch.cuda.synchronize()

@@ -7,7 +7,7 @@ import json
 import sys
 
 a1, a2, out = sys.argv[1:4]
-modes = [int(x) for x in (sys.argv[4] if len(sys.argv) > 4 else "1,2,3,4,5,6").split(",")]
+modes = [int(x) for x in (sys.argv[4] if len(sys.argv) > 4 else "1,2,3,4,5,6,7").split(",")]
 SHAPES = ["L=289, 16 heads, 32 sequences", "L=545, 12 heads, 32 sequences", "L=256 Swin window (+bias), 12 heads, 32 sequences",
           "L=50, 12 heads, 32 sequences (CLIP)"]
 PER = 13   # launches per (shape, mode): 3 warm-up + 10 timed
@@ -27,7 +27,7 @@ def load(root):
 d1, d2 = load(a1), load(a2)
 res = {"command": "tools/attn_pmc.sh: rocprofv3 --pmc <SQ counters> -- python3 tools/bench_attn.py (two passes), counters summed over the "
                   "13 launches of each (shape, attn_mode)", "kernel": "attn_f32_kernel<NBUF, UP>",
-       "modes": "odd = single K/V buffer (2 barriers per tile), even = double-buffered (1 barrier); 3,4 / 5,6 add the start-up stagger",
+       "modes": "odd = single K/V buffer (2 barriers per tile), even = double-buffered (1 barrier); 3,4 / 5,6 add the start-up stagger; 7 = three row blocks per workgroup (single buffer)",
        "configs": {}}
 i = 0
 for sh in SHAPES:
