@@ -957,7 +957,7 @@ extern "C" int sgic_split3_pack_f32(const float *d_x, int ld, int rows, int cols
   return sgic::check_launch("split3_rows_kernel<pack>");
 }
 
-#define SGIC_SPLIT3_TILE_MODES 25
+#define SGIC_SPLIT3_TILE_MODES 27
 
 template <int WAVES_M, int WAVES_N, int BM, int BN, int NS, int KS = 1, bool PERSIST = false>
 static int s3_launch(const S3Args &g, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
@@ -1080,14 +1080,18 @@ static int s3_dispatch(const S3Args &g, const sgic_launch_opts *opts, hipStream_
   }
   const auto *evp = prof_next(opts);
   hipEvent_t e0 = evp ? evp->first : nullptr, e1 = evp ? evp->second : nullptr;
-  if ((mode >= 6 && mode <= 9) || mode == 12 || mode == 13) {
+  if ((mode >= 6 && mode <= 9) || mode == 12 || mode == 13 || mode == 26 || mode == 27) {
     // modes 6 / 7 = modes 1 / 2 for the rows that fill WHOLE rounds of the 256 CUs + the 64x128 two-per-CU tiles for the rest,
     // as two launches (the first ends on a full round, so nothing idles at the seam): a last round of big tiles that covers a
     // fraction of the chip costs a whole tile time, the small tiles finish it in about half.  One profiler record spans both.
     // modes 8 / 9: the same split with the 32x32 latency tiles (64-k stages, three workgroups per CU) for the remaining rows
     // modes 12 / 13: as 8 / 9 with the whole rounds walked by the persistent launch (10 / 11)
-    const int big = mode >= 12 ? mode - 11 : (mode >= 8 ? mode - 7 : mode - 5), tail = mode >= 8 ? 4 : 5, TM = 128, TN = big == 1 ? 256 : 128;
-    const int big_mode = mode >= 12 ? big + 9 : big;
+    // modes 26 / 27: as 8 / 12 (128x256 for the whole rounds, plain / persistent) with the ring kernel's 80x64 tiles (mode 23) for the
+    // remaining rows: the remainder of M = 9 248 (1 056 rows x 1024 x 4096) takes 78 us there against 103 us with the 32x32 tiles
+    const bool ring_tail = mode >= 26;
+    const int cm = ring_tail ? (mode == 26 ? 8 : 12) : mode;
+    const int big = cm >= 12 ? cm - 11 : (cm >= 8 ? cm - 7 : cm - 5), tail = ring_tail ? 23 : (cm >= 8 ? 4 : 5), TM = 128, TN = big == 1 ? 256 : 128;
+    const int big_mode = cm >= 12 ? big + 9 : big;
     const long tiles_n = (N + TN - 1) / TN, tiles_m = (M + TM - 1) / TM;
     const long m_full = (tiles_m * tiles_n / 256) * 256 / tiles_n;   // m-tiles inside whole rounds
     const long m_split = m_full * TM;

@@ -22,10 +22,10 @@ def dispatches(rec):
     """kernel dispatches behind one profile record: the split GEMM's modes 6 / 7 are two launches when the grid has whole rounds
     of the 256 CUs plus a tail (csrc/gemm_split.hip: s3_dispatch)"""
     key, mode = rec[0], (rec[3] if len(rec) > 3 else None)
-    if not is_s3(key) or mode not in (6, 7, 8, 9, 12, 13):
+    if not is_s3(key) or mode not in (6, 7, 8, 9, 12, 13, 26, 27):
         return 1
     M, N = key[0], key[1]
-    tn = 256 if mode in (6, 8, 12) else 128
+    tn = 256 if mode in (6, 8, 12, 26, 27) else 128
     tiles_n, tiles_m = (N + tn - 1) // tn, (M + 127) // 128
     m_full = (tiles_m * tiles_n // 256) * 256 // tiles_n
     return 2 if (m_full > 0 and m_full * 128 < M) else 1
@@ -39,15 +39,17 @@ def tail_signature(rec):
     """(kernel name fragment, grid size in threads) of the SECOND launch of a split-launch record, or None.  The second launch covers the
     rows beyond the whole rounds with 32x32 tiles (modes 8 / 9 / 12 / 13: 4 waves) or 64x128 tiles (6 / 7: 8 waves)"""
     key, mode = rec[0], (rec[3] if len(rec) > 3 else None)
-    if not is_s3(key) or mode not in (6, 7, 8, 9, 12, 13) or (len(key) > 6 and key[6] == "conv"):
+    if not is_s3(key) or mode not in (6, 7, 8, 9, 12, 13, 26, 27) or (len(key) > 6 and key[6] == "conv"):
         return None
     M, N = key[0], key[1]
-    tn = 256 if mode in (6, 8, 12) else 128
+    tn = 256 if mode in (6, 8, 12, 26, 27) else 128
     tiles_n, tiles_m = (N + tn - 1) // tn, (M + 127) // 128
     m_full = (tiles_m * tiles_n // 256) * 256 // tiles_n
     if not (m_full > 0 and m_full * 128 < M):
         return None
     rows = M - m_full * 128
+    if mode in (26, 27):   # the ring kernel's 80x64 tiles
+        return "gemm_split3_ring_kernel<1, 4, 5, 1,", ((rows + 79) // 80) * ((N + 63) // 64) * 256
     if mode in (6, 7):
         return "gemm_split3_kernel<2, 4, 2, 2,", ((rows + 63) // 64) * ((N + 127) // 128) * 512
     return "gemm_split3_kernel<2, 2, 1, 1,", ((rows + 31) // 32) * ((N + 31) // 32) * 256
