@@ -267,7 +267,7 @@ def roofline_block(prof, ops, dev, dt, steps, flops_per_step, pmc_file, pmc_shap
             traffic = int((pj["hbm_fetch_MB_per_launch_x2_corrected"] + pj["hbm_write_MB_per_launch"]) * 1e6)
     except Exception:
         pass
-    blk = {"bound": "mfma", "kernel": "gemm_split3_dma_kernel (+ gemm_split3_kernel for the small tiles)" if dom_s3 else "gemm_f32_kernel", "achieved": round(achieved, 2), "peak": peak,
+    blk = {"bound": "mfma", "kernel": "gemm_split3_dma_kernel (+ gemm_split3_kernel / gemm_split3_ring_kernel for the small tiles)" if dom_s3 else "gemm_f32_kernel", "achieved": round(achieved, 2), "peak": peak,
            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
            "traffic_unit": f"bytes per launch (rocprofv3 PMC, profiles/{pmc_file})",
            "launches_per_step": n_launch // max(1, steps),
