@@ -95,11 +95,15 @@ template <int BM, int BN, int PASSES>
 __device__ __forceinline__ void s3_tile_epilogue(const S3Args &g, f32x4 (&acc)[BM][BN], float *ep, int em0, int en0, int wm, int wn, int lane) {
   const int l16 = lane & 15, lq = lane >> 4;
   if (g.vec_epilogue) {
-    constexpr int BMP = BM / PASSES, RM = 16 * BMP, CN = 16 * BN, LDW = CN + 4, LPR = CN / 4, RPI = 64 / LPR, NIT = RM / RPI;
-    static_assert(BM % PASSES == 0 && RM % RPI == 0, "epilogue passes");
+    // LPR lanes cover a row segment of the wave's tile, RPI rows per store instruction.  BN = 3 (the 128x192 tile: 48 columns per wave):
+    // 12 lanes per row, five rows per instruction on 60 lanes, seven instructions for 32 rows with the last one partial (EXACT = false)
+    constexpr int BMP = BM / PASSES, RM = 16 * BMP, CN = 16 * BN, LDW = CN + 4, LPR = CN / 4, RPI = 64 / LPR, NIT = (RM + RPI - 1) / RPI;
+    constexpr bool EXACT = (64 % LPR) == 0 && (RM % RPI) == 0;
+    static_assert(BM % PASSES == 0, "epilogue passes");
     const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
+    const bool lane_on = EXACT || lane < RPI * LPR;
     const int n = en0 + wn + c4;
-    const bool colok = n < g.N;
+    const bool colok = n < g.N && lane_on;
     const int nc = colok ? n : 0;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (g.bias && colok) bv = *reinterpret_cast<const f32x4 *>(g.bias + n);
@@ -120,12 +124,13 @@ __device__ __forceinline__ void s3_tile_epilogue(const S3Args &g, f32x4 (&acc)[B
           f32x4 cv[EB], rv[EB];
 #pragma unroll
           for (int q = 0; q < EB; ++q) {
-            const int rr = (b + q) * RPI + r0;
+            const int rr = EXACT ? (b + q) * RPI + r0 : min((b + q) * RPI + r0, RM - 1);   // (a clamped row is not stored: see below)
             cv[q] = *reinterpret_cast<const f32x4 *>(ep + rr * LDW + c4);
             if constexpr (HASR) rv[q] = *reinterpret_cast<const f32x4 *>(g.R + (size_t)(min(em0 + wmp + rr, g.M - 1) + g.m_base) * g.ldr + nc);
           }
 #pragma unroll
           for (int q = 0; q < EB; ++q) {
+            if (!EXACT && (b + q >= NIT || (b + q) * RPI + r0 >= RM)) continue;
             const int m = em0 + wmp + (b + q) * RPI + r0;
             f32x4 v = cv[q];
 #pragma unroll
@@ -586,8 +591,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1)
 void gemm_split3_dma_kernel(S3Args g) {
   constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW, TM = 16 * BM * WAVES_M, TN = 16 * BN * WAVES_N;
   constexpr int ROWB = 64;
-  constexpr int PA = TM / 16, PW = TN / 16, CA = PA / NW, CW = PW / NW;        // 1 KiB pieces per plane: of the tile / of one wave
-  static_assert(PA % NW == 0 && PW % NW == 0 && CA >= 1 && CW >= 1, "every wave moves whole pieces of both operands");
+  // 1 KiB pieces per plane: of the tile / of one wave.  When NW does not divide a count (the 128x192 tile: 12 W pieces, 8 waves) the last
+  // requests wrap around to pieces 0 .. -- the same bytes to the same LDS address twice, harmless -- so every wave issues the same count
+  constexpr int PA = TM / 16, PW = TN / 16, CA = (PA + NW - 1) / NW, CW = (PW + NW - 1) / NW;
   constexpr int APLANE = TM * ROWB, WPLANE = TN * ROWB, STAGE = 3 * (APLANE + WPLANE);
   constexpr int HB = BN / 2;
   static_assert(BN >= 2 && (BM % 2) == 0, "rotating fragment schedule");
@@ -631,16 +637,16 @@ void gemm_split3_dma_kernel(S3Args g) {
     baseW = g.W + (size_t)n0 * (g.w_packed ? 32 : g.K);
 #pragma unroll
     for (int i = 0; i < CA; i++) {
-      const int am = min(m0 + (wave + NW * i) * 16 + prow, g.M - 1);
+      const int am = min(m0 + ((wave + NW * i) % PA) * 16 + prow, g.M - 1);
       const size_t off = g.conv_C ? conv_off(am) : (size_t)am * astride;
       voffA[i] = (unsigned)((off - a0) * 2 + pslot * 16);
-      if ((S3_ABLATE & 192) == 64) voffA[i] = (unsigned)((wave + NW * i) * 1024 + lane * 16);   // diagnostic: bit 6 = operands read as if stored tile-packed (a piece = 1 KiB contiguous); bits 6+7 = W only
+      if ((S3_ABLATE & 192) == 64) voffA[i] = (unsigned)(((wave + NW * i) % PA) * 1024 + lane * 16);   // diagnostic: bit 6 = operands read as if stored tile-packed (a piece = 1 KiB contiguous); bits 6+7 = W only
     }
 #pragma unroll
     for (int i = 0; i < CW; i++) {
-      const int wr = min(n0 + (wave + NW * i) * 16 + prow, g.N - 1);
+      const int wr = min(n0 + ((wave + NW * i) % PW) * 16 + prow, g.N - 1);
       voffW[i] = (unsigned)(((size_t)(wr - n0) * (g.w_packed ? 32 : g.K)) * 2 + pslot * 16);
-      if (S3_ABLATE & 64) voffW[i] = (unsigned)((wave + NW * i) * 1024 + lane * 16);
+      if (S3_ABLATE & 64) voffW[i] = (unsigned)(((wave + NW * i) % PW) * 1024 + lane * 16);
     }
   };
   setup();
@@ -659,10 +665,10 @@ void gemm_split3_dma_kernel(S3Args g) {
       const char *pw = reinterpret_cast<const char *>(baseW + p * g.w_plane + ((S3_ABLATE & 64) ? (size_t)(k0 / 32) * (TN * 32) : (g.w_packed ? (size_t)k0 * g.N : (size_t)k0)));
 #pragma unroll
       for (int i = 0; i < CA; i++)
-        __builtin_amdgcn_global_load_lds((s3_glb_void *)(pa + voffA[i]), (s3_lds_void *)(stage + p * APLANE + (wave + NW * i) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((s3_glb_void *)(pa + voffA[i]), (s3_lds_void *)(stage + p * APLANE + ((wave + NW * i) % PA) * 1024), 16, 0, 0);
 #pragma unroll
       for (int i = 0; i < CW; i++)
-        __builtin_amdgcn_global_load_lds((s3_glb_void *)(pw + voffW[i]), (s3_lds_void *)(stage + 3 * APLANE + p * WPLANE + (wave + NW * i) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((s3_glb_void *)(pw + voffW[i]), (s3_lds_void *)(stage + 3 * APLANE + p * WPLANE + ((wave + NW * i) % PW) * 1024), 16, 0, 0);
     }
   };
   f32x4 acc[BM][BN];
@@ -957,7 +963,7 @@ extern "C" int sgic_split3_pack_f32(const float *d_x, int ld, int rows, int cols
   return sgic::check_launch("split3_rows_kernel<pack>");
 }
 
-#define SGIC_SPLIT3_TILE_MODES 27
+#define SGIC_SPLIT3_TILE_MODES 29
 
 template <int WAVES_M, int WAVES_N, int BM, int BN, int NS, int KS = 1, bool PERSIST = false>
 static int s3_launch(const S3Args &g, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
@@ -1041,6 +1047,10 @@ static int s3_mode(const S3Args &g, int mode, hipStream_t st, hipEvent_t e0, hip
 #ifndef S3_MICRO_BIG_ONLY   // diagnostic builds (tools/micro) instantiate the two kernels above only: minutes less of compile time
     case 14: return dma_ok ? s3_launch_dma<4, 2, 4, 4>(g, st, e0, e1) : s3_launch<2, 4, 2, 2, 1>(g, st, e0, e1);               // 256x128: the 128x256 tile's blocking for N = 128
     case 15: return dma_ok ? s3_launch_dma<4, 2, 4, 4, true>(g, st, e0, e1) : s3_launch<2, 4, 2, 2, 1>(g, st, e0, e1);
+    // 28 / 29: 128x192 (plain / persistent): N = 768 = 4 x 192 -- M = 8 192 is 64 x 4 = 256 tiles, ONE whole round, where 128x256 tiles
+    // are 192 (a quarter of the chip idle).  LDS-DMA staging only; otherwise the 128x128 register tile
+    case 28: return dma_ok ? s3_launch_dma<2, 4, 4, 3>(g, st, e0, e1) : s3_launch<2, 4, 4, 2, 1>(g, st, e0, e1);
+    case 29: return dma_ok ? s3_launch_dma<2, 4, 4, 3, true>(g, st, e0, e1) : s3_launch<2, 4, 4, 2, 1>(g, st, e0, e1);
     case 16: return dma_ok ? s3_launch_dma<2, 4, 4, 2>(g, st, e0, e1) : s3_launch<2, 4, 4, 2, 1>(g, st, e0, e1);
     case 17: return dma_ok ? s3_launch_dma<2, 4, 4, 2, true>(g, st, e0, e1) : s3_launch<2, 4, 4, 2, 1, 1, true>(g, st, e0, e1);
     case 2: return s3_launch<2, 4, 4, 2, 1>(g, st, e0, e1);
