@@ -332,8 +332,10 @@ SPLIT3_SMALL_M = 2048
 
 
 def _split3_modes(M):
-    """candidate launch modes of a split GEMM with M rows: the ring kernel's 32..64-row tiles are for single-image sized launches"""
+    """candidate launch modes of a split GEMM with M rows: the ring kernel's 32..80-row tiles are for single-image sized launches"""
     return SPLIT3_MODES if M <= SPLIT3_SMALL_M else tuple(m for m in SPLIT3_MODES if m not in SPLIT3_RING_MODES)
+
+
 _W3 = {}          # (data_ptr, N, K, ldw, version) -> (planes, w): the weight is pinned so its address cannot be reused
 _W3_BYTES = 0
 _W3_LIMIT = 24 << 30

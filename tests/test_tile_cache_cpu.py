@@ -105,3 +105,20 @@ def test_mode_ranges_agree_between_the_layers():
     assert max(ops.SPLIT3_MODES) == split_max == ops._MAX_MODE["gemm3"] == ops._MAX_MODE["conv3"]
     assert max(ops.TUNE_MODES) == f32_max == ops._MAX_MODE["gemm"] == ops._MAX_MODE["conv3x3"]
     assert max(ops.ATTN_MODES) == ops._MAX_MODE["attn"] == ops._MAX_MODE["attn3"] == 7
+
+
+def test_planes_rowmajor_inverts_the_slice_major_layout():
+    """ops.Planes.rowmajor() (what the GPU tests compare producers' planes through) is the inverse of csrc/split3.h: s3_pack_off --
+    element (row, col) of plane p sits at p * rows * cols + ((col / 32) * rows + row) * 32 + col % 32"""
+    import torch
+    import sgic_amd  # noqa
+    from sgic_amd import ops
+    rows, cols = 5, 96
+    pl = ops.Planes(rows, cols, torch.device("cpu"))
+    pl.t.copy_(torch.arange(3 * rows * cols, dtype=torch.int16))
+    rm = pl.rowmajor()
+    assert rm.shape == (3, rows, cols)
+    for p in range(3):
+        for r in range(rows):
+            for c in (0, 1, 31, 32, 63, 64, 95):
+                assert int(rm[p, r, c]) == p * rows * cols + ((c // 32) * rows + r) * 32 + c % 32
