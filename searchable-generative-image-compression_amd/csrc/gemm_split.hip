@@ -230,7 +230,8 @@ __device__ __forceinline__ void s3_tile_epilogue(const S3Args &g, f32x4 (&acc)[B
 // on the shader array itself, beside its dispatch timestamps.  No stamp executes in the product build.
 // S3_ABLATE (diagnostic builds of tools/micro/split3_phases.hip only; results are garbage): bit 0 = no global loads in the main
 // loop, bit 1 = no LDS writes, bit 2 = no barrier, bit 3 = no fragment reads -- what each part of the K loop costs beside the MFMAs;
-// bits 4 / 5 / 6 (LDS-DMA kernel): operand reads of tile (0,0) / (m,0) only; operands addressed as if stored tile-packed
+// bits 4 / 5 / 6 (LDS-DMA kernel): operand reads of tile (0,0) / (m,0) only; operands addressed as if stored tile-packed (6+7: W only);
+// bit 8: the third plane of both operands is not re-fetched after the first slice (a third fewer operand bytes per slice)
 #ifndef S3_ABLATE
 #define S3_ABLATE 0
 #endif
@@ -661,6 +662,7 @@ void gemm_split3_dma_kernel(S3Args g) {
     unsigned char *stage = smem + buf * STAGE;
 #pragma unroll
     for (int p = 0; p < 3; p++) {
+      if ((S3_ABLATE & 256) && p == 2 && k0 > 0) continue;   // diagnostic: bit 8 = a third fewer operand bytes per slice (what a 256x256 tile would move per flop)
       const char *pa = reinterpret_cast<const char *>(baseA + p * g.a_plane + (((S3_ABLATE & 192) == 64) ? (size_t)(k0 / 32) * (TM * 32) : ka));
       const char *pw = reinterpret_cast<const char *>(baseW + p * g.w_plane + ((S3_ABLATE & 64) ? (size_t)(k0 / 32) * (TN * 32) : (g.w_packed ? (size_t)k0 * g.N : (size_t)k0)));
 #pragma unroll

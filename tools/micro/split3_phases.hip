@@ -49,11 +49,11 @@ int main(int argc, char **argv) {
     hipMemcpy(W, h.data(), (size_t)sh.N * sh.K * 4, hipMemcpyHostToDevice);
     hipMemset(R, 0, (size_t)sh.M * sh.N * 4);
     hipMemset(bias, 0, (size_t)sh.N * 4);
-    sgic_split3_f32(A, sh.K, sh.M, sh.K, 0, 0, Ap, nullptr);
-    sgic_split3_f32(W, sh.K, sh.N, sh.K, 0, 0, Wp, nullptr);
+    sgic_split3_pack_f32(A, sh.K, sh.M, sh.K, Ap, nullptr);   // the slice-major layout the model uses (round 3); -DROWMAJOR for the old one
+    sgic_split3_pack_f32(W, sh.K, sh.N, sh.K, Wp, nullptr);
     for (int mode : modes) {
       if ((mode == 1 || mode == 10) && sh.N < 1024) continue;
-      sgic_launch_opts o{mode, 0, nullptr};
+      sgic_launch_opts o{mode, 0, nullptr, 1, 1};
       auto run = [&]() {
         return sgic_gemm_split3_f32(nullptr, 0, 0, 0, Ap, Wp, bias, sh.res ? R : nullptr, sh.N, C, sh.N, nullptr, sh.M, sh.N, sh.K, sh.act, 0, 0, &o, nullptr);
       };
