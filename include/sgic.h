@@ -230,7 +230,8 @@ int sgic_l2norm_u8(const float *d_x, int ldx, int M, int D, float *d_unit, uint8
  *   10 / 11 = 1 / 2 as a persistent launch (one resident workgroup per CU walks the tile list), 12 / 13 = 8 / 9 with the
  *   whole rounds walked persistently, 14 / 15 = 256x128 tiles (plain / persistent), 16 / 17 = 2 / 11 with LDS-DMA staging,
  *   18-25 = the ring kernel's small tiles (32x32 ... 80x64: single-image sized launches), 26 / 27 = 8 / 12 with the ring kernel's
- *   80x64 tiles for the remaining rows, 28 / 29 = 128x192 tiles (plain / persistent; N = 768: 8192 rows = one whole round).
+ *   80x64 tiles for the remaining rows, 28 / 29 = 128x192 tiles (plain / persistent; N = 768: 8192 rows = one whole round), 30 = 256x256 tiles
+ *   (W single-buffered in LDS), 31 = 30 for the rows that fill whole rounds + 1 for the rest.
  *   The 128x256 and 256x128 tiles (1, 10, 14, 15 and the whole-round part of 6, 8, 12) stage their operands by LDS-DMA
  *   (global_load_lds: no register pass, no ds_write), the other tiles through registers; all modes are bitwise identical. */
 int sgic_split3_f32(const float *d_x, int ld, int rows, int cols, int seg, int seg_stride, uint16_t *d_planes,

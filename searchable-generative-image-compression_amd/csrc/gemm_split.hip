@@ -587,7 +587,7 @@ void gemm_split3_kernel(S3Args g) {
 typedef __attribute__((address_space(3))) void s3_lds_void;
 typedef __attribute__((address_space(1))) const void s3_glb_void;
 
-template <int WAVES_M, int WAVES_N, int BM, int BN, bool PERSIST>
+template <int WAVES_M, int WAVES_N, int BM, int BN, bool PERSIST, bool WS1 = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1)
 void gemm_split3_dma_kernel(S3Args g) {
   constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW, TM = 16 * BM * WAVES_M, TN = 16 * BN * WAVES_N;
@@ -596,9 +596,15 @@ void gemm_split3_dma_kernel(S3Args g) {
   // requests wrap around to pieces 0 .. -- the same bytes to the same LDS address twice, harmless -- so every wave issues the same count
   constexpr int PA = TM / 16, PW = TN / 16, CA = (PA + NW - 1) / NW, CW = (PW + NW - 1) / NW;
   constexpr int APLANE = TM * ROWB, WPLANE = TN * ROWB, STAGE = 3 * (APLANE + WPLANE);
+  // WS1 (the 256x256 tile: two whole stages would be 192 KB): A double-buffered, W SINGLE-buffered -- a wave holds its W fragments of a
+  // slice in registers for the whole slice, so once every wave has read them (a second barrier, behind row 0's first MFMAs) the W region
+  // takes slice kt + 1 while slice kt is still being multiplied.  LDS image: A stage 0 | A stage 1 | W.
+  constexpr int ASTAGE = WS1 ? 3 * APLANE : STAGE, WOFF = WS1 ? 6 * APLANE : 3 * APLANE, WSTAGE = WS1 ? 0 : STAGE;
+  constexpr int LDS_TOTAL = WS1 ? 6 * APLANE + 3 * WPLANE : 2 * STAGE;
+  static_assert(!(WS1 && PERSIST), "the single W buffer has no room for the next tile's first slice during the epilogue");
   constexpr int HB = BN / 2;
   static_assert(BN >= 2 && (BM % 2) == 0, "rotating fragment schedule");
-  static_assert(NW * (16 * BM / 2) * (16 * BN + 4) * 4 <= STAGE, "the two-pass epilogue must fit one staging buffer");
+  static_assert(NW * (16 * BM / 2) * (16 * BN + 4) * 4 <= (WS1 ? LDS_TOTAL : STAGE), "the two-pass epilogue must fit one staging buffer (WS1: the whole LDS)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef S3_STAMPS
   const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime(), st_c0 = __builtin_amdgcn_s_memtime();
@@ -659,7 +665,7 @@ void gemm_split3_dma_kernel(S3Args g) {
       const int tap = k0 / g.conv_C, c0 = k0 - tap * g.conv_C, ky = tap / 3, kx = tap - 3 * ky;
       ka = g.a_packed ? ((size_t)(c0 >> 5) * g.a_rows + ky * (g.conv_W + 2) + kx) * 32 : (size_t)((ky * (g.conv_W + 2) + kx) * g.conv_C + c0);
     }
-    unsigned char *stage = smem + buf * STAGE;
+    unsigned char *stageA = smem + buf * ASTAGE, *stageW = smem + WOFF + buf * WSTAGE;
 #pragma unroll
     for (int p = 0; p < 3; p++) {
       if ((S3_ABLATE & 256) && p == 2 && k0 > 0) continue;   // diagnostic: bit 8 = a third fewer operand bytes per slice (what a 256x256 tile would move per flop)
@@ -667,24 +673,24 @@ void gemm_split3_dma_kernel(S3Args g) {
       const char *pw = reinterpret_cast<const char *>(baseW + p * g.w_plane + ((S3_ABLATE & 64) ? (size_t)(k0 / 32) * (TN * 32) : (g.w_packed ? (size_t)k0 * g.N : (size_t)k0)));
 #pragma unroll
       for (int i = 0; i < CA; i++)
-        __builtin_amdgcn_global_load_lds((s3_glb_void *)(pa + voffA[i]), (s3_lds_void *)(stage + p * APLANE + ((wave + NW * i) % PA) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((s3_glb_void *)(pa + voffA[i]), (s3_lds_void *)(stageA + p * APLANE + ((wave + NW * i) % PA) * 1024), 16, 0, 0);
 #pragma unroll
       for (int i = 0; i < CW; i++)
-        __builtin_amdgcn_global_load_lds((s3_glb_void *)(pw + voffW[i]), (s3_lds_void *)(stage + 3 * APLANE + p * WPLANE + ((wave + NW * i) % PW) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((s3_glb_void *)(pw + voffW[i]), (s3_lds_void *)(stageW + p * WPLANE + ((wave + NW * i) % PW) * 1024), 16, 0, 0);
     }
   };
   f32x4 acc[BM][BN];
   const int l16 = lane & 15, lq = lane >> 4;
   const int foff = l16 * ROWB + ((lq ^ swz(l16)) * 16);
-  const int abase = wm * ROWB, bbase = 3 * APLANE + wn * ROWB;
+  const int abase = wm * ROWB, bbase = WOFF + wn * ROWB;
   bf16x8 wf[3][BN], af[2][3];
   auto read_w = [&](int buf, int j) __attribute__((always_inline)) {
-    const unsigned char *base = smem + buf * STAGE + bbase + j * 16 * ROWB + foff;
+    const unsigned char *base = smem + buf * WSTAGE + bbase + j * 16 * ROWB + foff;
 #pragma unroll
     for (int p = 0; p < 3; p++) wf[p][j] = *reinterpret_cast<const bf16x8 *>(base + p * WPLANE);
   };
   auto read_a = [&](int buf, int i, int set) __attribute__((always_inline)) {
-    const unsigned char *base = smem + buf * STAGE + abase + i * 16 * ROWB + foff;
+    const unsigned char *base = smem + buf * ASTAGE + abase + i * 16 * ROWB + foff;
 #pragma unroll
     for (int p = 0; p < 3; p++) af[set][p] = *reinterpret_cast<const bf16x8 *>(base + p * APLANE);
   };
@@ -720,7 +726,7 @@ void gemm_split3_dma_kernel(S3Args g) {
   // reads of the current stage are done), and the MFMAs left cover the first fragment reads of the next stage
   auto slice = [&](int kt, bool more) __attribute__((always_inline)) {
     const int cur = kt & 1, nxt = cur ^ 1;
-    if (more) dma((kt + 1) * 32, nxt);
+    if (!WS1 && more) dma((kt + 1) * 32, nxt);
 #pragma unroll
     for (int j = 0; j < BN - HB; j++) read_w(cur, j);       // Wlo: needed after the Whi blocks of row 0
 #pragma unroll
@@ -729,6 +735,13 @@ void gemm_split3_dma_kernel(S3Args g) {
       if (i + 1 < BM) read_a(cur, i + 1, set ^ 1);
 #pragma unroll
       for (int j = BN - HB; j < BN; j++) block(i, j, set);
+      if (WS1 && i == 0) {
+        // every W fragment of this slice is in registers once the Wlo reads above have landed: behind a barrier the W region is free for
+        // slice kt + 1 (row 0's Whi MFMAs are in the pipe meanwhile)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (more) dma((kt + 1) * 32, nxt);
+      }
       if (i == BM - 1) {
         constexpr int NMF1 = 6 * (BM * BN - (BN - HB)), NDMA = 3 * (CA + CW), NDR1 = 3 * (BN - HB) + 3 * (BM - 1);
         if constexpr (!(S3_DMA_VARIANT & 1)) {
@@ -779,7 +792,7 @@ void gemm_split3_dma_kernel(S3Args g) {
       }
     }
     // the epilogue's LDS slice lives in the stage-1 region (stage 0 may be receiving the next tile)
-    s3_tile_epilogue<BM, BN, 2>(g, acc, reinterpret_cast<float *>(smem + STAGE) + wave * ((16 * BM / 2) * (16 * BN + 4)), em0, en0, wm, wn, lane);
+    s3_tile_epilogue<BM, BN, 2>(g, acc, reinterpret_cast<float *>(smem + (WS1 ? 0 : STAGE)) + wave * ((16 * BM / 2) * (16 * BN + 4)), em0, en0, wm, wn, lane);
 #ifdef S3_STAMPS
     {
       const unsigned long long ph3 = __builtin_amdgcn_s_memtime();
@@ -965,7 +978,7 @@ extern "C" int sgic_split3_pack_f32(const float *d_x, int ld, int rows, int cols
   return sgic::check_launch("split3_rows_kernel<pack>");
 }
 
-#define SGIC_SPLIT3_TILE_MODES 29
+#define SGIC_SPLIT3_TILE_MODES 31
 
 template <int WAVES_M, int WAVES_N, int BM, int BN, int NS, int KS = 1, bool PERSIST = false>
 static int s3_launch(const S3Args &g, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
@@ -991,12 +1004,13 @@ static int s3_launch(const S3Args &g, hipStream_t st, hipEvent_t ev_start, hipEv
   return sgic::check_launch("gemm_split3_kernel");
 }
 
-template <int WAVES_M, int WAVES_N, int BM, int BN, bool PERSIST = false>
+template <int WAVES_M, int WAVES_N, int BM, int BN, bool PERSIST = false, bool WS1 = false>
 static int s3_launch_dma(const S3Args &g, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
   constexpr int NT = 64 * WAVES_M * WAVES_N, TM = 16 * BM * WAVES_M, TN = 16 * BN * WAVES_N;
-  constexpr int LDS = 2 * 3 * (TM + TN) * 64;
+  constexpr int LDS = WS1 ? 3 * (2 * TM + TN) * 64 : 2 * 3 * (TM + TN) * 64;
+  static_assert(LDS <= 160 * 1024, "LDS of a CU");
   static bool attr_set[64] = {};   // per device, as s3_launch
-  auto kernel = gemm_split3_dma_kernel<WAVES_M, WAVES_N, BM, BN, PERSIST>;
+  auto kernel = gemm_split3_dma_kernel<WAVES_M, WAVES_N, BM, BN, PERSIST, WS1>;
   int dev = 0;
   SGIC_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {
@@ -1053,6 +1067,8 @@ static int s3_mode(const S3Args &g, int mode, hipStream_t st, hipEvent_t e0, hip
     // are 192 (a quarter of the chip idle).  LDS-DMA staging only; otherwise the 128x128 register tile
     case 28: return dma_ok ? s3_launch_dma<2, 4, 4, 3>(g, st, e0, e1) : s3_launch<2, 4, 4, 2, 1>(g, st, e0, e1);
     case 29: return dma_ok ? s3_launch_dma<2, 4, 4, 3, true>(g, st, e0, e1) : s3_launch<2, 4, 4, 2, 1>(g, st, e0, e1);
+    // 30: 256x256 (W single-buffered: 144 KB): a third fewer operand bytes per flop than 128x256
+    case 30: return dma_ok ? s3_launch_dma<2, 4, 8, 4, false, true>(g, st, e0, e1) : s3_launch<2, 4, 2, 2, 1>(g, st, e0, e1);
     case 16: return dma_ok ? s3_launch_dma<2, 4, 4, 2>(g, st, e0, e1) : s3_launch<2, 4, 4, 2, 1>(g, st, e0, e1);
     case 17: return dma_ok ? s3_launch_dma<2, 4, 4, 2, true>(g, st, e0, e1) : s3_launch<2, 4, 4, 2, 1, 1, true>(g, st, e0, e1);
     case 2: return s3_launch<2, 4, 4, 2, 1>(g, st, e0, e1);
@@ -1092,6 +1108,22 @@ static int s3_dispatch(const S3Args &g, const sgic_launch_opts *opts, hipStream_
   }
   const auto *evp = prof_next(opts);
   hipEvent_t e0 = evp ? evp->first : nullptr, e1 = evp ? evp->second : nullptr;
+  if (mode == 31) {
+    // 31: 256x256 tiles (mode 30) for the rows that fill WHOLE rounds of the 256 CUs + 128x256 tiles (mode 1) for the rest
+    const long tiles_n = (N + 255) / 256, tiles_m = (M + 255) / 256;
+    const long m_full = (tiles_m * tiles_n / 256) * 256 / tiles_n, m_split = m_full * 256;
+    if (m_full > 0 && m_split < M && !g.conv_C) {
+      S3Args g1 = g, g2 = g;
+      g1.M = (int)m_split;
+      g2.M = M - (int)m_split;
+      g2.A += g.a_packed ? m_split * 32 : m_split * K;
+      g2.m_base = (int)m_split;
+      int rc = s3_mode(g1, 30, st, e0, nullptr);
+      if (rc) return rc;
+      return s3_mode(g2, 1, st, nullptr, e1);
+    }
+    mode = 30;
+  }
   if ((mode >= 6 && mode <= 9) || mode == 12 || mode == 13 || mode == 26 || mode == 27) {
     // modes 6 / 7 = modes 1 / 2 for the rows that fill WHOLE rounds of the 256 CUs + the 64x128 two-per-CU tiles for the rest,
     // as two launches (the first ends on a full round, so nothing idles at the seam): a last round of big tiles that covers a

@@ -102,7 +102,7 @@ def _remember(key, mode, dirty=True):
     _DIRTY = _DIRTY or dirty
 
 
-_MAX_MODE = {"gemm": 15, "conv3x3": 15, "gemm3": 29, "conv3": 29, "attn": 7, "attn3": 7}   # per kind of key
+_MAX_MODE = {"gemm": 15, "conv3x3": 15, "gemm3": 31, "conv3": 31, "attn": 7, "attn3": 7}   # per kind of key
 
 
 def _load_tile_cache():
@@ -326,7 +326,7 @@ PROFILE_TILES = []     # launch mode actually used by each record of the current
 # depend on (N, K) and on the operands' kinds, never on M, so single-image and batched requests stay bitwise identical.
 PRECISION = os.environ.get("SGIC_GEMM", "split3")
 assert PRECISION in ("f32", "split3"), f"SGIC_GEMM={PRECISION!r}: expected f32 or split3"
-SPLIT3_MODES = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29)
+SPLIT3_MODES = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31)
 SPLIT3_RING_MODES = (18, 19, 20, 21, 22, 23, 24, 25)   # small tiles, deep LDS-DMA ring: raced only for launches that cannot fill the chip (_split3_modes)
 SPLIT3_SMALL_M = 2048
 

@@ -192,7 +192,7 @@ def test_split_launch_modes_with_row_map_residual_and_planes(ops):
     bias = torch.randn(N, device="cuda", generator=g)
     r = torch.randn(M, N, device="cuda", generator=g)
     ref = {}
-    for tile in (1, 6, 7, 8, 9, 10, 11, 12, 13, 16, 17, 26, 27, 28, 29):
+    for tile in (1, 6, 7, 8, 9, 10, 11, 12, 13, 16, 17, 26, 27, 28, 29, 30, 31):
         out = torch.zeros(n * L, N, device="cuda")
         ops.gemm(a, w, bias, out=out, M=M, c_seg=(Lt, L), precision="split3", tile=tile)
         y = ops.gemm(a, w, bias, residual=r, act=ops.ACT_SILU, precision="split3", tile=tile)
@@ -204,7 +204,7 @@ def test_split_launch_modes_with_row_map_residual_and_planes(ops):
             ops.set_precision(old)
         torch.cuda.synchronize()
         ref[tile] = (out.clone(), y.clone(), pl.t.clone())
-    for tile in (6, 7, 8, 9, 10, 11, 12, 13, 16, 17, 26, 27, 28, 29):
+    for tile in (6, 7, 8, 9, 10, 11, 12, 13, 16, 17, 26, 27, 28, 29, 30, 31):
         assert all(torch.equal(p, q) for p, q in zip(ref[1], ref[tile])), tile
     o3 = ref[1][0].reshape(n, L, N)
     want = (a.double() @ w.double().T + bias.double()).reshape(n, Lt, N)
@@ -269,7 +269,7 @@ def test_row_major_and_slice_major_planes_agree(ops):
     bias = torch.randn(N, device="cuda", generator=g)
     ref = ops.gemm(a, w, bias, precision="split3", tile=2)
     planes = {(0, "a"): ops.split3(a), (0, "w"): ops.split3(w), (1, "a"): ops.split3_planes(a).t, (1, "w"): ops.split3_planes(w).t}
-    for tile in (1, 5, 19, 23, 4, 8, 27):
+    for tile in (1, 5, 19, 23, 4, 8, 27, 30, 31):
         for apk in (0, 1):
             for wpk in (0, 1):
                 out = torch.empty(M, N, device="cuda")

@@ -30,7 +30,7 @@ def test_in_tree_cache_is_well_formed():
     for k, v in d["picks"].items():
         kind, *nums = k.split("|")
         assert kind in ("gemm", "gemm3", "conv3x3", "conv3", "attn", "attn3") and all(n.lstrip("-").isdigit() for n in nums)
-        assert 0 <= int(v) <= {"attn": 7, "attn3": 7, "gemm3": 29, "conv3": 29}.get(kind, 15)
+        assert 0 <= int(v) <= {"attn": 7, "attn3": 7, "gemm3": 31, "conv3": 31}.get(kind, 15)
     # the dominant GEMM shapes of the benchmarked configuration are covered: no process races them again
     for key in ("gemm|9248|4096|1024|0|1", "gemm|9248|1024|4096|1|0", "gemm|9248|3072|1024|0|0", "attn|32|289|16|0",
                 "gemm3|9248|4096|1024|0|1", "gemm3|9248|1024|4096|1|0", "gemm3|9248|3072|1024|0|0"):   # gemm3: the bf16x3 split GEMM

@@ -22,6 +22,10 @@ def dispatches(rec):
     """kernel dispatches behind one profile record: the split GEMM's modes 6 / 7 are two launches when the grid has whole rounds
     of the 256 CUs plus a tail (csrc/gemm_split.hip: s3_dispatch)"""
     key, mode = rec[0], (rec[3] if len(rec) > 3 else None)
+    if is_s3(key) and mode == 31:
+        tiles_n, tiles_m = (key[1] + 255) // 256, (key[0] + 255) // 256
+        m_full = (tiles_m * tiles_n // 256) * 256 // tiles_n
+        return 2 if (m_full > 0 and m_full * 256 < key[0]) else 1
     if not is_s3(key) or mode not in (6, 7, 8, 9, 12, 13, 26, 27):
         return 1
     M, N = key[0], key[1]
@@ -39,6 +43,12 @@ def tail_signature(rec):
     """(kernel name fragment, grid size in threads) of the SECOND launch of a split-launch record, or None.  The second launch covers the
     rows beyond the whole rounds with 32x32 tiles (modes 8 / 9 / 12 / 13: 4 waves) or 64x128 tiles (6 / 7: 8 waves)"""
     key, mode = rec[0], (rec[3] if len(rec) > 3 else None)
+    if is_s3(key) and mode == 31 and not (len(key) > 6 and key[6] == "conv"):   # 256x256 whole rounds + 128x256 tiles for the rest
+        tiles_n, tiles_m = (key[1] + 255) // 256, (key[0] + 255) // 256
+        m_full = (tiles_m * tiles_n // 256) * 256 // tiles_n
+        if not (m_full > 0 and m_full * 256 < key[0]):
+            return None
+        return "gemm_split3_dma_kernel<2, 4, 4, 4, false", ((key[0] - m_full * 256 + 127) // 128) * tiles_n * 512
     if not is_s3(key) or mode not in (6, 7, 8, 9, 12, 13, 26, 27) or (len(key) > 6 and key[6] == "conv"):
         return None
     M, N = key[0], key[1]

@@ -17,7 +17,7 @@ SMALL = "--small" in sys.argv
 ATTN = "--attn" in sys.argv
 OUT = os.path.join(ROOT, "gpurun_out", "retune_attn.json" if ATTN else ("retune_small.json" if SMALL else "retune_big.json"))
 SMALL_MODES = (3, 4, 5, 18, 19, 20, 21, 22, 23, 24, 25)
-GEMM_MODES = (1, 2, 5, 6, 7, 8, 9, 10, 11, 12, 13, 16, 17, 26, 27, 28, 29)
+GEMM_MODES = (1, 2, 5, 6, 7, 8, 9, 10, 11, 12, 13, 16, 17, 26, 27, 28, 29, 30, 31)
 CONV_MODES = (1, 2, 3, 5, 10, 11, 14, 15, 16, 17)
 
 
@@ -93,7 +93,7 @@ def main():
             r = torch.randn(M, N, device=dev, generator=g) if res else None
             ap = ops.split3_planes(a)
             out = torch.empty(M, N, device=dev)
-            modes = list(SMALL_MODES) if SMALL else [m for m in GEMM_MODES if not (m in (1, 6, 8, 10, 12, 26, 27) and N < 256) and not (m in (28, 29) and N < 192)]
+            modes = list(SMALL_MODES) if SMALL else [m for m in GEMM_MODES if not (m in (1, 6, 8, 10, 12, 26, 27, 30, 31) and N < 256) and not (m in (28, 29) and N < 192)]
             t = race(lambda m: ops.gemm(ap, w, b, residual=r, act=act, out=out, tile=m, precision="split3"), modes)
             fl = 2.0 * M * N * K
         elif kind == "conv3":
