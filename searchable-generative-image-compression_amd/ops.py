@@ -815,7 +815,7 @@ def conv3x3(x_halo, w, bias, B, H, W, Cin, Cout, residual=None, act=ACT_NONE, ou
             launch3(tile)
         else:
             key = ("conv3", B * H * W, H, W, Cin, Cout, int(residual is not None), act)
-            if _pick_and_launch(key, launch3, B * H * W * Cout >= (1 << 20), modes=(1, 2, 3, 5, 10, 11, 14, 15, 16, 17)):
+            if _pick_and_launch(key, launch3, B * H * W * Cout >= (1 << 20), modes=(1, 2, 3, 5, 10, 11, 14, 15, 16, 17, 30)):
                 return out
         if PROFILE is not None:
             PROFILE.append((2.0 * B * H * W * Cout * 9 * Cin, (B * H * W, Cout, 9 * Cin, residual is not None, act, "s3", "conv")))

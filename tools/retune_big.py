@@ -18,7 +18,7 @@ ATTN = "--attn" in sys.argv
 OUT = os.path.join(ROOT, "gpurun_out", "retune_attn.json" if ATTN else ("retune_small.json" if SMALL else "retune_big.json"))
 SMALL_MODES = (3, 4, 5, 18, 19, 20, 21, 22, 23, 24, 25)
 GEMM_MODES = (1, 2, 5, 6, 7, 8, 9, 10, 11, 12, 13, 16, 17, 26, 27, 28, 29, 30, 31)
-CONV_MODES = (1, 2, 3, 5, 10, 11, 14, 15, 16, 17)
+CONV_MODES = (1, 2, 3, 5, 10, 11, 14, 15, 16, 17, 30)
 
 
 def merge():
@@ -109,7 +109,7 @@ def main():
             hp = ops.halo_planes_buffer(dev, B, H, W, Cin)
             ops.split3_planes(halo.view(-1, Cin), out=ops.Planes(halo.numel() // Cin, Cin, dev, buf=hp.t))
             out = torch.empty(M, Cout, device=dev)
-            modes = [m for m in CONV_MODES if not (m in (1, 10) and Cout < 256)]
+            modes = [m for m in CONV_MODES if not (m in (1, 10, 30) and Cout < 256)]
             t = race(lambda m: ops.conv3x3(hp, w, b, B, H, W, Cin, Cout, residual=r, act=act, out=out, tile=m, precision="split3"), modes)
             fl = 2.0 * M * Cout * 9 * Cin
             del halo
