@@ -14,7 +14,8 @@
 // term order a3w1, a1w3, a2w2, a2w1, a1w2, a1w1): no split-K, and the same for every tile shape below, so results are bitwise
 // independent of M, of the tile choice and of the batch a row sits in (batch-invariant), like gemm.hip.
 //
-// Operands arrive PRE-SPLIT as three bf16 planes [3][rows][K]: weights once at load time, activations by
+// Operands arrive PRE-SPLIT as three bf16 planes -- slice-major [3][K / 32][rows][32] (split3.h; round 3) or row-major [3][rows][K],
+// per operand (S3Args.a_packed / w_packed): weights once at load time, activations by
 // split3_rows_kernel (or directly by the producing kernel).  The GEMM kernel is then a pure bf16 pipeline:
 //  * tile (16 BM WAVES_M) x (16 BN WAVES_N), K slices of 32, two LDS stages; rows are 64 B (32 k) unpadded, 16-byte slots
 //    XOR-swizzled per 4-row group: conflict-free ds_read_b128 / ds_write_b128;
@@ -67,7 +68,7 @@ __device__ __forceinline__ void s3_for(F &&f) {   // f(IntC<0>) ... f(IntC<N-1>)
 }
 
 struct S3Args {
-  const unsigned short *A, *W;   // planes [3][M][K], [3][N][K]
+  const unsigned short *A, *W;   // planes [3][M][K], [3][N][K] (row-major) or slice-major: a_packed / w_packed below
   const float *bias, *R;
   float *C;
   int M, N, K, ldr, ldc, act;
