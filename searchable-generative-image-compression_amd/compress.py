@@ -237,8 +237,10 @@ def main(argv=None):
         host_ms["gpu_gap_between_batches"] = sum(gpu_evs[i][1].elapsed_time(gpu_evs[i + 1][0]) for i in range(1, len(gpu_evs) - 1)) / max(1, len(gpu_evs) - 2) * host_ms.get("batches", 1)
 
     # every rank reaches this point, failed or not: the error flag travels first so that nobody blocks in the gather
+    # (collective operands live on the device for RCCL; the gloo backend -- CPU rehearsals, several ranks sharing one card -- takes host tensors)
+    cdev = dev if not distributed or dist.get_backend() == "nccl" else torch.device("cpu")
     if distributed:
-        flag = torch.tensor([1.0 if failed is not None else 0.0], device=dev)
+        flag = torch.tensor([1.0 if failed is not None else 0.0], device=cdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if float(flag.item()) > 0:
             dist.destroy_process_group()
@@ -248,8 +250,8 @@ def main(argv=None):
             return 1
     elif failed is not None:
         raise failed
-    allv = gather_vectors(torch.from_numpy(vecs).to(dev), len(files), rank, world).cpu().numpy()
-    rate = torch.tensor([len(mine) / dt if dt > 0 else 0.0], device=dev, dtype=torch.float64)
+    allv = gather_vectors(torch.from_numpy(vecs).to(cdev), len(files), rank, world).cpu().numpy()
+    rate = torch.tensor([len(mine) / dt if dt > 0 else 0.0], device=cdev, dtype=torch.float64)
     if distributed:
         dist.all_reduce(rate, op=dist.ReduceOp.SUM)
     if rank == 0:

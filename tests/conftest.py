@@ -57,13 +57,27 @@ def pytest_sessionstart(session):
     proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "compress.py"), "--dataset_dir", src, "--save_dir",
                              os.path.join(root, "out"), "--small", "--batch_size", "4"], env=env, stdout=log, stderr=subprocess.STDOUT,
                             cwd=ROOT)
-    session.config._sgic_rccl_child = {"proc": proc, "root": root, "log": log.name, "src": src}
+    # the same CLI as a TWO-rank job on this one card (backend gloo, both ranks on cuda:0): shards, the gather and rank 0's index
+    # assembly with more than one process, on real GPU outputs (tests/test_gpu_rccl.py compares it with the 1-rank job's files)
+    port2 = _free_port()
+    two = []
+    for r in range(2):
+        env2 = dict(os.environ, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port2),
+                    SGIC_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        lg = open(os.path.join(root, f"two_rank{r}.log"), "w")
+        two.append((subprocess.Popen([sys.executable, os.path.join(ROOT, "compress.py"), "--dataset_dir", src, "--save_dir",
+                                      os.path.join(root, "out2"), "--small", "--batch_size", "2"], env=env2, stdout=lg,
+                                     stderr=subprocess.STDOUT, cwd=ROOT), lg.name))
+    session.config._sgic_rccl_child = {"proc": proc, "root": root, "log": log.name, "src": src, "two": two}
 
 
 def pytest_sessionfinish(session, exitstatus):
     ch = getattr(session.config, "_sgic_rccl_child", None)
     if ch and ch["proc"].poll() is None:
         ch["proc"].kill()          # the exact child this session started
+    for pr, _ in (ch or {}).get("two", []):
+        if pr.poll() is None:
+            pr.kill()
 
 
 @pytest.fixture(scope="session")

@@ -36,6 +36,30 @@ def test_cli_under_one_rank_rccl_child_process(rccl_child, tmp_path):
     print(f"[rccl] 1-rank nccl job: {rec}")
 
 
+def test_two_rank_job_on_one_card_matches_the_one_rank_job(rccl_child):
+    """compress.py as a TWO-rank job (backend gloo, both ranks on this card; started by conftest): each rank compresses its
+    contiguous shard, the CLIP vectors are gathered, rank 0 assembles the index -- and every output file is byte-identical to the
+    1-rank RCCL job's (same kernels, M-invariant arithmetic: a shard of 3 images gives the streams a run of 6 gives)"""
+    if rccl_child is None:
+        pytest.skip("started by conftest at session start of a `-m gpu` run")
+    logs = []
+    for pr, lg in rccl_child["two"]:
+        rc = pr.wait(timeout=900)
+        logs.append(open(lg).read())
+        assert rc == 0, logs[-1][-3000:]
+    assert rccl_child["proc"].wait(timeout=900) == 0
+    rec = json.loads([ln for ln in logs[0].splitlines() if ln.startswith("{")][-1])
+    assert rec["collectives"] == "gloo" and rec["images"] == 6 and rec["n_gpus"] == 2, rec
+    one, two = os.path.join(rccl_child["root"], "out"), os.path.join(rccl_child["root"], "out2")
+    for sub, names in (("bitstreams", [f"im{i}.c2df" for i in range(6)]), ("clip_vecs", [f"im{i}.npy" for i in range(6)]),
+                       ("faiss", ["index.faiss"])):
+        for n in names:
+            assert open(os.path.join(one, sub, n), "rb").read() == open(os.path.join(two, sub, n), "rb").read(), (sub, n)
+    ids = [[os.path.basename(x) for x in open(os.path.join(d, "faiss", "ids.txt")).read().split()] for d in (one, two)]   # doc ids carry the save dir
+    assert ids[0] == ids[1] and len(ids[0]) == 6
+    print(f"[gloo x2 on one card] {rec}")
+
+
 def _dim(index_bytes):
     return int(np.frombuffer(index_bytes[4:8], dtype="<i4")[0])
 
